@@ -1,0 +1,87 @@
+// Library-level entry points: error string, ABI version, and the fused predict_and_render_radiance
+// forward (reference nerf/train_utils.py:92-202) sequenced on one stream from the per-stage kernels.
+#include <cstring>
+
+#include "dn_common.h"
+
+namespace dn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
+struct Workspace {
+  float *z_c, *rf_c, *w_c, *z_f, *rf_f;
+  size_t bytes;
+};
+
+static Workspace carve(void* base, int64_t n, int nc, int nf) {
+  Workspace w{};
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr;
+    off += align256(floats * sizeof(float));
+    return p;
+  };
+  w.z_c = take(static_cast<size_t>(n) * nc);
+  w.rf_c = take(static_cast<size_t>(n) * nc * 4);
+  w.w_c = take(static_cast<size_t>(n) * nc);
+  if (nf > 0) {
+    w.z_f = take(static_cast<size_t>(n) * (nc + nf));
+    w.rf_f = take(static_cast<size_t>(n) * (nc + nf) * 4);
+  }
+  w.bytes = off;
+  return w;
+}
+
+}  // namespace dn
+
+using namespace dn;
+
+extern "C" int dn_abi_version(void) { return DN_ABI_VERSION; }
+
+extern "C" const char* dn_last_error(void) { return g_err; }
+
+extern "C" size_t dn_render_workspace_bytes(int64_t n_rays, int num_coarse, int num_fine) {
+  if (n_rays < 0 || num_coarse < 1 || num_fine < 0) return 0;
+  return carve(nullptr, n_rays, num_coarse, num_fine).bytes;
+}
+
+extern "C" int dn_render_rays(const dn_mlp_desc* desc_coarse, const void* packed_coarse, const dn_mlp_desc* desc_fine,
+                              const void* packed_fine, int precision, const float* rays, int ray_stride,
+                              int64_t n_rays, int num_coarse, int num_fine, int lindisp, float noise_std,
+                              int white_background, const float* h_m_thres, int n_thres, const float* t_rand,
+                              const float* noise_c, const float* u, const float* noise_f, float* rgb_c,
+                              float* depth_c, float* acc_c, float* rgb_f, float* depth_f, float* acc_f, float* dex_f,
+                              void* workspace, dn_stream_t stream) {
+  DN_REQUIRE(desc_coarse && packed_coarse && rays && workspace && n_rays >= 0, "dn_render_rays: bad arguments");
+  DN_REQUIRE(num_fine == 0 || (desc_fine && packed_fine), "dn_render_rays: fine pass requested without a fine net");
+  DN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "dn_render_rays: workspace must be 256-byte aligned");
+  if (n_rays == 0) return 0;
+  Workspace w = carve(workspace, n_rays, num_coarse, num_fine);
+  int rc;
+  if ((rc = dn_coarse_depths(rays, ray_stride, n_rays, num_coarse, lindisp, t_rand, w.z_c, stream))) return rc;
+  if ((rc = dn_run_network(desc_coarse, precision, packed_coarse, nullptr, nullptr, rays, ray_stride, w.z_c, n_rays,
+                           num_coarse, w.rf_c, stream)))
+    return rc;
+  const bool fine = num_fine > 0;
+  // Dex depths come from the fine pass (train_utils.py:199-201); coarse-only renders report the coarse ones.
+  if ((rc = dn_volume_render(w.rf_c, w.z_c, rays + 3, ray_stride, noise_c, noise_std, white_background, h_m_thres,
+                             fine ? 0 : n_thres, n_rays, num_coarse, rgb_c, nullptr, acc_c, w.w_c, depth_c,
+                             fine ? nullptr : dex_f, stream)))
+    return rc;
+  if (!fine) return 0;
+  if ((rc = dn_fine_depths(w.z_c, w.w_c, u, n_rays, num_coarse, num_fine, w.z_f, nullptr, stream))) return rc;
+  if ((rc = dn_run_network(desc_fine, precision, packed_fine, nullptr, nullptr, rays, ray_stride, w.z_f, n_rays,
+                           num_coarse + num_fine, w.rf_f, stream)))
+    return rc;
+  return dn_volume_render(w.rf_f, w.z_f, rays + 3, ray_stride, noise_f, noise_std, white_background, h_m_thres, n_thres,
+                          n_rays, num_coarse + num_fine, rgb_f, nullptr, acc_f, nullptr, depth_f, dex_f, stream);
+}

@@ -1,0 +1,90 @@
+// Shared host/device helpers for libdexnerf_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/dexnerf_hip.h"
+
+namespace dn {
+
+constexpr int kWave = 64;
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(dn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Launch check: hipGetLastError after enqueue (no sync, graph-capture safe).
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return -static_cast<int>(e);
+  }
+  return 0;
+}
+
+#define DN_REQUIRE(cond, ...)     \
+  do {                            \
+    if (!(cond)) {                \
+      dn::set_error(__VA_ARGS__); \
+      return DN_E_INVAL;          \
+    }                             \
+  } while (0)
+
+// ---- wave-level primitives (DPP-lowered shuffles; 64 lanes) --------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// inclusive scans across the 64 lanes of a wave
+__device__ __forceinline__ double wave_scan_mul(double v) {
+  const int l = lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double t = __shfl_up(v, o, 64);
+    if (l >= o) v *= t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ double wave_scan_add(double v) {
+  const int l = lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double t = __shfl_up(v, o, 64);
+    if (l >= o) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float wave_scan_add(float v) {
+  const int l = lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_up(v, o, 64);
+    if (l >= o) v += t;
+  }
+  return v;
+}
+
+// torch.linspace(start, end, steps) element i on CPU, fp32 (FMA form)
+__host__ __device__ __forceinline__ float linspace_elem(float start, float end, int steps, int i) {
+  if (steps == 1) return start;
+  const float step = (end - start) / static_cast<float>(steps - 1);
+  return (i < steps / 2) ? fmaf(step, static_cast<float>(i), start)
+                         : fmaf(-step, static_cast<float>(steps - 1 - i), end);
+}
+
+}  // namespace dn

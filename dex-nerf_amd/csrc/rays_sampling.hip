@@ -1,0 +1,350 @@
+// Ray generation, coarse depths, standalone positional encoding, inverse-CDF sampler and the
+// coarse+fine depth merge.  HBM-bound elementwise / wave-scan kernels (one wave64 per ray for the
+// sampler); compiled with -ffp-contract=off so plain mul/add sequences round like ATen's.
+#include "dn_common.h"
+
+namespace dn {
+
+// ------------------------------------------------------------------------------------------------
+// S1 get_ray_bundle (reference nerf/nerf_helpers.py:67-112)
+// ------------------------------------------------------------------------------------------------
+struct RayBundleArgs {
+  float rinv[9];
+  float origin[3];
+  float fx, cx, cy;
+  int height, width;
+};
+
+__global__ void ray_bundle_kernel(RayBundleArgs a, float* __restrict__ ro, float* __restrict__ rd) {
+  const int64_t pix = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t total = static_cast<int64_t>(a.height) * a.width;
+  if (pix >= total) return;
+  const int row = static_cast<int>(pix / a.width);
+  const int col = static_cast<int>(pix - static_cast<int64_t>(row) * a.width);
+  // dir = [(ii-cx)/fx, (jj-cy)/fx, 1]: fx divides the y term too (nerf_helpers.py:100-101)
+  const float d0 = (static_cast<float>(col) - a.cx) / a.fx;
+  const float d1 = (static_cast<float>(row) - a.cy) / a.fx;
+  const float d2 = 1.0f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    // sum over the last dim of dir[None,:] * Rinv  ->  ((p0 + p1) + p2), products rounded first
+    const float p0 = d0 * a.rinv[3 * j + 0];
+    const float p1 = d1 * a.rinv[3 * j + 1];
+    const float p2 = d2 * a.rinv[3 * j + 2];
+    rd[pix * 3 + j] = (p0 + p1) + p2;
+    ro[pix * 3 + j] = a.origin[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S3 coarse depths (reference nerf/train_utils.py:111-133)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float coarse_z_at(float near, float far, int nc, int i, int lindisp) {
+  const float t = linspace_elem(0.0f, 1.0f, nc, i);
+  if (!lindisp) return near * (1.0f - t) + far * t;
+  return 1.0f / (1.0f / near * (1.0f - t) + 1.0f / far * t);
+}
+
+__global__ void coarse_depths_kernel(const float* __restrict__ rays, int ray_stride, int64_t n_rays, int nc,
+                                     int lindisp, const float* __restrict__ t_rand, float* __restrict__ z) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= n_rays * nc) return;
+  const int64_t r = idx / nc;
+  const int i = static_cast<int>(idx - r * nc);
+  const float near = rays[r * ray_stride + 6];
+  const float far = rays[r * ray_stride + 7];
+  const float zi = coarse_z_at(near, far, nc, i, lindisp);
+  if (t_rand == nullptr) {
+    z[idx] = zi;
+    return;
+  }
+  const float z_last = coarse_z_at(near, far, nc, nc - 1, lindisp);
+  const float z_first = coarse_z_at(near, far, nc, 0, lindisp);
+  const float upper = (i < nc - 1) ? 0.5f * (coarse_z_at(near, far, nc, i + 1, lindisp) + zi) : z_last;
+  const float lower = (i > 0) ? 0.5f * (zi + coarse_z_at(near, far, nc, i - 1, lindisp)) : z_first;
+  z[idx] = lower + (upper - lower) * t_rand[idx];
+}
+
+// ------------------------------------------------------------------------------------------------
+// S5 positional_encoding (reference nerf/nerf_helpers.py:115-159)
+// ------------------------------------------------------------------------------------------------
+struct FreqArgs {
+  float f[32];
+};
+
+__global__ void posenc_kernel(const float* __restrict__ x, int64_t n_elems, int dim, int num_fns, int include_input,
+                              FreqArgs fr, float* __restrict__ out) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= n_elems) return;
+  const int64_t p = idx / dim;
+  const int c = static_cast<int>(idx - p * dim);
+  const int width = dim * ((include_input ? 1 : 0) + 2 * num_fns);
+  float* o = out + p * width;
+  const float v = x[idx];
+  int base = 0;
+  if (include_input) {
+    o[c] = v;
+    base = dim;
+  }
+  for (int k = 0; k < num_fns; ++k) {
+    const float arg = v * fr.f[k];
+    o[base + (2 * k) * dim + c] = sinf(arg);
+    o[base + (2 * k + 1) * dim + c] = cosf(arg);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S7 sample_pdf_2 (reference nerf/nerf_helpers.py:262-304) + searchsorted(side="right")
+//   One wave64 per ray.  Bit-exact index recipe:
+//     sum  : ATen-CPU association order (8-lane vectors, 4 ILP accumulators, cascade levels);
+//     cdf  : fp64 prefix sums rounded to fp32 per element - here a wave-level fp64 scan, which is
+//            bit-identical to the sequential one because every partial sum of <=2^6 fp32 pdf values
+//            in [2^-24, 1] is exactly representable in fp64 (no rounding happens at all);
+//     inds : count of cdf entries <= u (upper bound by binary search over the LDS-resident cdf).
+// ------------------------------------------------------------------------------------------------
+constexpr int kSamplerWaves = 4;  // rays per 256-thread block
+
+// ATen multi_row_sum / row_sum / vectorized_inner_sum order for a contiguous fp32 row of length L held
+// in LDS.  Lanes 0..7 each own one vector lane; the result is broadcast to the whole wave.
+__device__ float aten_order_sum(const float* w, int L) {
+  const int lane = lane_id();
+  const int nvec = L >> 3;
+  const int groups = nvec >> 2;
+  float part = 0.0f;
+  if (lane < 8) {
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
+    int ceil_log2 = 0;
+    while ((1 << ceil_log2) < groups) ++ceil_log2;
+    const int level_power = max(4, ceil_log2 / 4);
+    const int level_step = 1 << level_power;
+    const int level_mask = level_step - 1;
+    int i = 0;
+    for (; i + level_step <= groups;) {
+      for (int j = 0; j < level_step; ++j, ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[0][k] += w[(i * 4 + k) * 8 + lane];
+      }
+      for (int j = 1; j < 4; ++j) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc[j][k] += acc[j - 1][k];
+          acc[j - 1][k] = 0.0f;
+        }
+        const int mask = level_mask << (j * level_power);
+        if ((i & mask) != 0) break;
+      }
+    }
+    for (; i < groups; ++i) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[0][k] += w[(i * 4 + k) * 8 + lane];
+    }
+    for (int j = 1; j < 4; ++j) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[0][k] += acc[j][k];
+    }
+    for (int v = groups * 4; v < nvec; ++v) acc[0][0] += w[v * 8 + lane];
+    part = ((acc[0][0] + acc[0][1]) + acc[0][2]) + acc[0][3];
+  }
+  float total = 0.0f;
+  for (int k = nvec * 8; k < L; ++k) total += w[k];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) total += __shfl(part, k, 64);
+  return total;  // identical in every lane
+}
+
+// Builds cdf[0..B) in LDS from w[0..B-1) (already +1e-5) ; w is overwritten with the pdf.
+__device__ void build_cdf(float* w, float* cdf, int B) {
+  const int lane = lane_id();
+  const int L = B - 1;
+  const float s = aten_order_sum(w, L);
+  double carry = 0.0;
+  if (lane == 0) cdf[0] = 0.0f;
+  for (int base = 0; base < L; base += 64) {
+    const int i = base + lane;
+    const float pdf = (i < L) ? w[i] / s : 0.0f;
+    const double inc = wave_scan_add(static_cast<double>(pdf)) + carry;
+    if (i < L) cdf[i + 1] = static_cast<float>(inc);
+    carry = __shfl(inc, 63, 64);
+  }
+}
+
+__device__ __forceinline__ float invert_cdf(const float* cdf, const float* bins, int B, float u, int* ind_out) {
+  int lo = 0, hi = B;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+  }
+  *ind_out = lo;
+  const int below = max(lo - 1, 0);
+  const int above = min(lo, B - 1);
+  const float cb = cdf[below], ca = cdf[above];
+  const float bb = bins[below], ba = bins[above];
+  float denom = ca - cb;
+  if (denom < 1e-5f) denom = 1.0f;
+  const float t = (u - cb) / denom;
+  return bb + t * (ba - bb);
+}
+
+// mode 0: bins/weights given (dn_sample_pdf).  mode 1: z_coarse/weights_coarse given (dn_fine_depths):
+// bins = z_mid, w = weights[1:-1], then z_fine = sort(cat(z_coarse, samples)).
+template <int MODE>
+__global__ __launch_bounds__(256) void sampler_kernel(const float* __restrict__ bins_or_z, const float* __restrict__ weights,
+                                                      const float* __restrict__ u, int64_t n_rays, int B, int nf,
+                                                      float* __restrict__ samples, int64_t* __restrict__ inds,
+                                                      float* __restrict__ z_fine, int sort_len) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
+  const int64_t ray_raw = static_cast<int64_t>(blockIdx.x) * kSamplerWaves + wave;
+  const bool live = ray_raw < n_rays;
+  const int64_t ray = live ? ray_raw : (n_rays - 1);
+  const int per_wave = 3 * (B + 1) + sort_len;
+  float* w = lds + wave * per_wave;   // B-1 used
+  float* cdf = w + (B + 1);           // B
+  float* bins = cdf + (B + 1);        // B
+  float* sbuf = bins + (B + 1);       // sort_len (MODE 1)
+  const int L = B - 1;
+  if (MODE == 0) {
+    for (int i = lane; i < B; i += 64) bins[i] = bins_or_z[ray * B + i];
+    for (int i = lane; i < L; i += 64) w[i] = weights[ray * L + i] + 1e-5f;
+  } else {
+    const int nc = B + 1;
+    const float* zc = bins_or_z + ray * nc;
+    for (int i = lane; i < B; i += 64) bins[i] = 0.5f * (zc[i + 1] + zc[i]);
+    for (int i = lane; i < L; i += 64) w[i] = weights[ray * nc + 1 + i] + 1e-5f;
+    for (int i = lane; i < nc; i += 64) sbuf[i] = zc[i];
+  }
+  __syncthreads();
+  build_cdf(w, cdf, B);
+  __syncthreads();
+  for (int q = lane; q < nf; q += 64) {
+    const float uq = (u != nullptr) ? u[ray * nf + q] : linspace_elem(0.0f, 1.0f, nf, q);
+    int ind;
+    const float s = invert_cdf(cdf, bins, B, uq, &ind);
+    if (live) {
+      if (samples != nullptr) samples[ray * nf + q] = s;
+      if (inds != nullptr) inds[ray * nf + q] = ind;
+    }
+    if (MODE == 1) sbuf[B + 1 + q] = s;
+  }
+  if (MODE == 1) {
+    const int total = B + 1 + nf;
+    for (int i = total + lane; i < sort_len; i += 64) sbuf[i] = __builtin_inff();
+    // bitonic sort of sort_len (power of two) floats by one wave; block-uniform trip counts
+    for (int k = 2; k <= sort_len; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        __syncthreads();
+        for (int t = lane; t < (sort_len >> 1); t += 64) {
+          const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int hi = lo | j;
+          const bool up = ((lo & k) == 0);
+          const float a = sbuf[lo], b = sbuf[hi];
+          if ((a > b) == up) {
+            sbuf[lo] = b;
+            sbuf[hi] = a;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (live)
+      for (int i = lane; i < total; i += 64) z_fine[ray * total + i] = sbuf[i];
+  }
+}
+
+static int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+}  // namespace dn
+
+using namespace dn;
+
+extern "C" int dn_ray_bundle(int height, int width, const float* h_rinv9, const float* h_origin3, float fx, float cx,
+                             float cy, float* ro, float* rd, dn_stream_t stream) {
+  DN_REQUIRE(height > 0 && width > 0 && h_rinv9 && h_origin3 && ro && rd, "dn_ray_bundle: bad arguments");
+  RayBundleArgs a;
+  for (int i = 0; i < 9; ++i) a.rinv[i] = h_rinv9[i];
+  for (int i = 0; i < 3; ++i) a.origin[i] = h_origin3[i];
+  a.fx = fx; a.cx = cx; a.cy = cy; a.height = height; a.width = width;
+  const int64_t total = static_cast<int64_t>(height) * width;
+  const int block = 256;
+  const unsigned grid = static_cast<unsigned>((total + block - 1) / block);
+  hipLaunchKernelGGL(ray_bundle_kernel, dim3(grid), dim3(block), 0, as_stream(stream), a, ro, rd);
+  return check_launch("dn_ray_bundle");
+}
+
+extern "C" int dn_coarse_depths(const float* rays, int ray_stride, int64_t n_rays, int num_coarse, int lindisp,
+                                const float* t_rand, float* z_vals, dn_stream_t stream) {
+  DN_REQUIRE(rays && z_vals && n_rays >= 0 && num_coarse >= 1 && ray_stride >= 8, "dn_coarse_depths: bad arguments");
+  if (n_rays == 0) return 0;
+  const int64_t total = n_rays * num_coarse;
+  const int block = 256;
+  const unsigned grid = static_cast<unsigned>((total + block - 1) / block);
+  hipLaunchKernelGGL(coarse_depths_kernel, dim3(grid), dim3(block), 0, as_stream(stream), rays, ray_stride, n_rays,
+                     num_coarse, lindisp, t_rand, z_vals);
+  return check_launch("dn_coarse_depths");
+}
+
+namespace dn {
+// frequency bands as the reference builds them (nerf_helpers.py:134-149): 2**linspace(0, L-1, L) or
+// linspace(1, 2**(L-1), L), fp32.
+void fill_freqs(float* f, int num_fns, int log_sampling) {
+  for (int k = 0; k < num_fns; ++k) {
+    if (log_sampling) {
+      f[k] = exp2f(linspace_elem(0.0f, static_cast<float>(num_fns - 1), num_fns, k));
+    } else {
+      f[k] = linspace_elem(1.0f, exp2f(static_cast<float>(num_fns - 1)), num_fns, k);
+    }
+  }
+}
+}  // namespace dn
+
+extern "C" int dn_positional_encoding(const float* x, int64_t n_points, int dim, int num_fns, int include_input,
+                                      int log_sampling, float* out, dn_stream_t stream) {
+  DN_REQUIRE(x && out && n_points >= 0 && dim >= 1 && num_fns >= 0 && num_fns <= 32,
+             "dn_positional_encoding: bad arguments (num_fns must be in [0,32])");
+  DN_REQUIRE(include_input || num_fns > 0, "dn_positional_encoding: empty encoding");
+  if (n_points == 0) return 0;
+  FreqArgs fr;
+  fill_freqs(fr.f, num_fns, log_sampling);
+  const int64_t total = n_points * dim;
+  const int block = 256;
+  const unsigned grid = static_cast<unsigned>((total + block - 1) / block);
+  hipLaunchKernelGGL(posenc_kernel, dim3(grid), dim3(block), 0, as_stream(stream), x, total, dim, num_fns,
+                     include_input, fr, out);
+  return check_launch("dn_positional_encoding");
+}
+
+extern "C" int dn_sample_pdf(const float* bins, const float* weights, const float* u, int64_t n_rays, int n_bins,
+                             int n_samples, float* samples, int64_t* inds, dn_stream_t stream) {
+  DN_REQUIRE(bins && weights && samples && n_rays >= 0 && n_samples >= 1, "dn_sample_pdf: bad arguments");
+  DN_REQUIRE(n_bins >= 9 && n_bins <= 512, "dn_sample_pdf: n_bins must be in [9, 512] (weights row >= 8 wide)");
+  if (n_rays == 0) return 0;
+  const size_t lds = static_cast<size_t>(kSamplerWaves) * 3 * (n_bins + 1) * sizeof(float);
+  const unsigned grid = static_cast<unsigned>((n_rays + kSamplerWaves - 1) / kSamplerWaves);
+  hipLaunchKernelGGL(sampler_kernel<0>, dim3(grid), dim3(256), lds, as_stream(stream), bins, weights, u, n_rays,
+                     n_bins, n_samples, samples, inds, static_cast<float*>(nullptr), 0);
+  return check_launch("dn_sample_pdf");
+}
+
+extern "C" int dn_fine_depths(const float* z_coarse, const float* weights, const float* u, int64_t n_rays,
+                              int num_coarse, int num_fine, float* z_fine, float* z_samples, dn_stream_t stream) {
+  DN_REQUIRE(z_coarse && weights && z_fine && n_rays >= 0 && num_fine >= 1, "dn_fine_depths: bad arguments");
+  DN_REQUIRE(num_coarse >= 10 && num_coarse <= 512 && num_coarse + num_fine <= 2048,
+             "dn_fine_depths: need 10 <= num_coarse <= 512 and num_coarse + num_fine <= 2048");
+  if (n_rays == 0) return 0;
+  const int B = num_coarse - 1;
+  const int sort_len = next_pow2(num_coarse + num_fine);
+  const size_t lds = static_cast<size_t>(kSamplerWaves) * (3 * (B + 1) + sort_len) * sizeof(float);
+  const unsigned grid = static_cast<unsigned>((n_rays + kSamplerWaves - 1) / kSamplerWaves);
+  hipLaunchKernelGGL(sampler_kernel<1>, dim3(grid), dim3(256), lds, as_stream(stream), z_coarse, weights, u, n_rays, B,
+                     num_fine, z_samples, static_cast<int64_t*>(nullptr), z_fine, sort_len);
+  return check_launch("dn_fine_depths");
+}

@@ -1,0 +1,111 @@
+"""ctypes binding of libdexnerf_hip.so (C ABI declared in include/dexnerf_hip.h).
+
+No torch types cross the boundary: tensors are passed as raw device pointers (`tensor.data_ptr()`) plus
+sizes, and work is enqueued on PyTorch's current HIP stream.  The library is REQUIRED for any device
+tensor: there is no eager/CPU fallback - `lib()` raises if the shared object is missing.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("DEXNERF_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libdexnerf_hip.so"))
+
+PREC_F32 = 0
+PREC_BF16 = 1
+
+EXPORTS = (
+    "dn_abi_version", "dn_last_error", "dn_ray_bundle", "dn_coarse_depths", "dn_positional_encoding",
+    "dn_mlp_packed_bytes", "dn_mlp_pack", "dn_run_network", "dn_mlp_forward_encoded", "dn_volume_render",
+    "dn_volume_render_backward", "dn_sample_pdf", "dn_fine_depths", "dn_render_workspace_bytes", "dn_render_rays",
+)
+
+
+class MlpDesc(ctypes.Structure):
+    """dn_mlp_desc (mirrors FlexibleNeRFModel.__init__, reference nerf/models.py:186-196)."""
+    _fields_ = [(n, c_int32) for n in (
+        "num_layers", "hidden_size", "skip_connect_every", "num_encoding_fn_xyz", "num_encoding_fn_dir",
+        "include_input_xyz", "include_input_dir", "use_viewdirs", "log_sampling_xyz", "log_sampling_dir")]
+
+
+_lib = None
+
+
+def _declare(lib):
+    fp, vp = c_void_p, c_void_p  # device pointers travel as integers
+    lib.dn_abi_version.restype = c_int
+    lib.dn_last_error.restype = c_char_p
+    lib.dn_ray_bundle.argtypes = [c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float, c_float, fp, fp, vp]
+    lib.dn_coarse_depths.argtypes = [fp, c_int, c_int64, c_int, c_int, fp, fp, vp]
+    lib.dn_positional_encoding.argtypes = [fp, c_int64, c_int, c_int, c_int, c_int, fp, vp]
+    lib.dn_mlp_packed_bytes.argtypes = [POINTER(MlpDesc), c_int]
+    lib.dn_mlp_packed_bytes.restype = c_size_t
+    lib.dn_mlp_pack.argtypes = [POINTER(MlpDesc), c_int, POINTER(c_void_p), POINTER(c_void_p), vp, vp]
+    lib.dn_run_network.argtypes = [POINTER(MlpDesc), c_int, vp, fp, fp, fp, c_int, fp, c_int64, c_int, fp, vp]
+    lib.dn_mlp_forward_encoded.argtypes = [POINTER(MlpDesc), c_int, vp, fp, c_int64, fp, vp]
+    lib.dn_volume_render.argtypes = [fp, fp, fp, c_int, fp, c_float, c_int, POINTER(c_float), c_int, c_int64, c_int,
+                                     fp, fp, fp, fp, fp, fp, vp]
+    lib.dn_volume_render_backward.argtypes = [fp, fp, fp, c_int, fp, c_float, c_int, c_int64, c_int, fp, fp, fp, fp,
+                                              fp, fp, vp]
+    lib.dn_sample_pdf.argtypes = [fp, fp, fp, c_int64, c_int, c_int, fp, fp, vp]
+    lib.dn_fine_depths.argtypes = [fp, fp, fp, c_int64, c_int, c_int, fp, fp, vp]
+    lib.dn_render_workspace_bytes.argtypes = [c_int64, c_int, c_int]
+    lib.dn_render_workspace_bytes.restype = c_size_t
+    lib.dn_render_rays.argtypes = [POINTER(MlpDesc), vp, POINTER(MlpDesc), vp, c_int, fp, c_int, c_int64, c_int, c_int,
+                                   c_int, c_float, c_int, POINTER(c_float), c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp,
+                                   fp, fp, vp, vp]
+    for name in EXPORTS:
+        if name not in ("dn_last_error", "dn_mlp_packed_bytes", "dn_render_workspace_bytes"):
+            getattr(lib, name).restype = c_int
+
+
+def lib():
+    """The loaded library; raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libdexnerf_hip.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C dex-nerf_amd/csrc`).  The HIP path has no fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        _declare(handle)
+        if handle.dn_abi_version() != 1:
+            raise RuntimeError("libdexnerf_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().dn_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what or 'dexnerf_hip'} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "HIP entry points need contiguous device tensors"
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def host_floats(values):
+    arr = (c_float * max(len(values), 1))(*[float(v) for v in values])
+    return arr
+
+
+def f32c(t):
+    """Contiguous fp32 view/copy of a device tensor."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

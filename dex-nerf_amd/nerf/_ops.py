@@ -1,0 +1,235 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point) + autograd glue.
+
+Every function here requires ROCm device tensors and calls straight into libdexnerf_hip.so; there is
+no alternative implementation behind them.
+"""
+import ctypes
+from ctypes import c_void_p
+
+import torch
+
+from . import _hip
+from ._hip import MlpDesc, check, f32c, host_floats, lib, ptr, stream
+
+_precision = _hip.PREC_F32
+
+
+def set_precision(name):
+    """'fp32' (exact fp32 MFMA chains, the parity mode) or 'bf16' (bf16 MFMA, fp32 accumulate)."""
+    global _precision
+    _precision = {"fp32": _hip.PREC_F32, "f32": _hip.PREC_F32, "bf16": _hip.PREC_BF16}[str(name).lower()]
+
+
+def get_precision():
+    return "bf16" if _precision == _hip.PREC_BF16 else "fp32"
+
+
+def _row_view(t):
+    """(pointer, row stride in floats) of a (N,3)-like fp32 view whose last dim is contiguous."""
+    assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
+    return c_void_p(t.data_ptr()), int(t.stride(0))
+
+
+# ------------------------------------------------------------------------------------------------
+def ray_bundle(height, width, rinv, origin, fx, cx, cy, device):
+    ro = torch.empty((height, width, 3), dtype=torch.float32, device=device)
+    rd = torch.empty_like(ro)
+    check(lib().dn_ray_bundle(height, width, host_floats(rinv), host_floats(origin), float(fx), float(cx), float(cy),
+                              ptr(ro), ptr(rd), stream()), "dn_ray_bundle")
+    return ro, rd
+
+
+def coarse_depths(rays, num_coarse, lindisp, t_rand=None):
+    rays = f32c(rays)
+    n = rays.shape[0]
+    z = torch.empty((n, num_coarse), dtype=torch.float32, device=rays.device)
+    tr = None if t_rand is None else f32c(t_rand)
+    check(lib().dn_coarse_depths(ptr(rays), rays.shape[1], n, num_coarse, int(bool(lindisp)), ptr(tr), ptr(z),
+                                 stream()), "dn_coarse_depths")
+    return z
+
+
+def positional_encoding(x, num_fns, include_input=True, log_sampling=True):
+    shape = x.shape
+    dim = shape[-1]
+    xf = f32c(x).reshape(-1, dim)
+    width = dim * ((1 if include_input else 0) + 2 * num_fns)
+    out = torch.empty((xf.shape[0], width), dtype=torch.float32, device=x.device)
+    check(lib().dn_positional_encoding(ptr(xf), xf.shape[0], dim, num_fns, int(bool(include_input)),
+                                       int(bool(log_sampling)), ptr(out), stream()), "dn_positional_encoding")
+    return out.reshape(*shape[:-1], width)
+
+
+# ------------------------------------------------------------------------------------------------
+class PackedMLP:
+    """MFMA fragment stream of one FlexibleNeRFModel, rebuilt when the parameters change."""
+
+    def __init__(self, desc_kwargs, device, precision=None):
+        self.desc = MlpDesc(**{k: int(v) for k, v in desc_kwargs.items()})
+        self.precision = _precision if precision is None else precision
+        nbytes = lib().dn_mlp_packed_bytes(ctypes.byref(self.desc), self.precision)
+        if nbytes == 0:
+            check(-1001, "dn_mlp_packed_bytes")
+        self.buffer = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.key = None
+
+    def pack(self, weights, biases):
+        """weights/biases: lists of device tensors in the reference parameter order."""
+        n = len(weights)
+        ws = [f32c(w.detach()) for w in weights]
+        bs = [f32c(b.detach()) for b in biases]
+        wp = (c_void_p * n)(*[w.data_ptr() for w in ws])
+        bp = (c_void_p * n)(*[b.data_ptr() for b in bs])
+        check(lib().dn_mlp_pack(ctypes.byref(self.desc), self.precision, wp, bp, ptr(self.buffer), stream()), "dn_mlp_pack")
+        self._keep = (ws, bs)  # keep sources alive until the pack kernel has run on this stream
+
+
+def run_network_pts(packed, pts, viewdirs, samples_per_ray):
+    pts = f32c(pts).reshape(-1, 3)
+    n_pts = pts.shape[0]
+    assert n_pts % samples_per_ray == 0
+    out = torch.empty((n_pts, 4), dtype=torch.float32, device=pts.device)
+    vd = None if viewdirs is None else f32c(viewdirs).reshape(-1, 3)
+    check(lib().dn_run_network(ctypes.byref(packed.desc), packed.precision, ptr(packed.buffer), ptr(pts), ptr(vd), None, 0,
+                               None, n_pts // samples_per_ray, samples_per_ray, ptr(out), stream()), "dn_run_network")
+    return out
+
+
+def run_network_rays(packed, rays, z_vals):
+    rays, z_vals = f32c(rays), f32c(z_vals)
+    n, s = z_vals.shape
+    out = torch.empty((n, s, 4), dtype=torch.float32, device=rays.device)
+    check(lib().dn_run_network(ctypes.byref(packed.desc), packed.precision, ptr(packed.buffer), None, None, ptr(rays),
+                               rays.shape[1], ptr(z_vals), n, s, ptr(out), stream()), "dn_run_network")
+    return out
+
+
+def mlp_forward_encoded(packed, x):
+    x = f32c(x)
+    shape = x.shape
+    xf = x.reshape(-1, shape[-1])
+    out = torch.empty((xf.shape[0], 4), dtype=torch.float32, device=x.device)
+    check(lib().dn_mlp_forward_encoded(ctypes.byref(packed.desc), packed.precision, ptr(packed.buffer), ptr(xf),
+                                       xf.shape[0], ptr(out), stream()), "dn_mlp_forward_encoded")
+    return out.reshape(*shape[:-1], 4)
+
+
+# ------------------------------------------------------------------------------------------------
+def volume_render_fwd(rf, z, rd, noise, noise_std, white, m_thres, want_weights=True):
+    rf, z = f32c(rf), f32c(z)
+    n, s = z.shape
+    dev = rf.device
+    rd = rd if (rd.dtype == torch.float32 and rd.dim() == 2 and rd.stride(1) == 1) else f32c(rd).reshape(-1, 3)
+    rd_ptr, rd_stride = _row_view(rd)
+    k = len(m_thres)
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((n,), dtype=torch.float32, device=dev)
+    acc = torch.empty_like(disp)
+    depth = torch.empty_like(disp)
+    weights = torch.empty((n, s), dtype=torch.float32, device=dev) if want_weights else None
+    dex = torch.empty((k, n), dtype=torch.float32, device=dev) if k else None
+    nz = None if (noise is None or noise_std <= 0.0) else f32c(noise)
+    check(lib().dn_volume_render(ptr(rf), ptr(z), rd_ptr, rd_stride, ptr(nz), float(noise_std), int(bool(white)),
+                                 host_floats(m_thres), k, n, s, ptr(rgb), ptr(disp), ptr(acc), ptr(weights), ptr(depth),
+                                 ptr(dex), stream()), "dn_volume_render")
+    return rgb, disp, acc, weights, depth, dex
+
+
+def volume_render_bwd(rf, z, rd, noise, noise_std, white, g_rgb, g_depth, g_acc, g_disp, g_weights):
+    rf, z = f32c(rf), f32c(z)
+    n, s = z.shape
+    rd = rd if (rd.dtype == torch.float32 and rd.dim() == 2 and rd.stride(1) == 1) else f32c(rd).reshape(-1, 3)
+    rd_ptr, rd_stride = _row_view(rd)
+    g_rf = torch.empty((n, s, 4), dtype=torch.float32, device=rf.device)
+    nz = None if (noise is None or noise_std <= 0.0) else f32c(noise)
+    gs = [None if g is None else f32c(g) for g in (g_rgb, g_depth, g_acc, g_disp, g_weights)]
+    check(lib().dn_volume_render_backward(ptr(rf), ptr(z), rd_ptr, rd_stride, ptr(nz), float(noise_std), int(bool(white)),
+                                          n, s, ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]), ptr(g_rf),
+                                          stream()), "dn_volume_render_backward")
+    return g_rf
+
+
+class VolumeRenderFn(torch.autograd.Function):
+    """Differentiable w.r.t. the radiance field only: depths and directions carry no gradient on this path
+    (the reference detaches z_samples, train_utils.py:170)."""
+
+    @staticmethod
+    def forward(ctx, rf, z, rd, noise, noise_std, white, m_thres):
+        rgb, disp, acc, weights, depth, dex = volume_render_fwd(rf, z, rd, noise, noise_std, white, m_thres)
+        ctx.save_for_backward(rf, z, rd, noise if noise is not None else torch.empty(0, device=rf.device))
+        ctx.cfg = (float(noise_std), bool(white), noise is not None)
+        outs = (rgb, disp, acc, weights, depth) + ((dex,) if dex is not None else ())
+        if dex is not None:
+            ctx.mark_non_differentiable(dex)
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_weights, g_depth, *_):
+        rf, z, rd, noise = ctx.saved_tensors
+        noise_std, white, has_noise = ctx.cfg
+
+        def nz(g):
+            return None if g is None else g.contiguous()
+        g_rf = volume_render_bwd(rf, z, rd, noise if has_noise else None, noise_std, white, nz(g_rgb), nz(g_depth),
+                                 nz(g_acc), nz(g_disp), nz(g_weights))
+        return g_rf, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+def sample_pdf(bins, weights, num_samples, u=None, want_inds=False):
+    bins, weights = f32c(bins), f32c(weights)
+    n, b = bins.shape
+    assert weights.shape == (n, b - 1)
+    samples = torch.empty((n, num_samples), dtype=torch.float32, device=bins.device)
+    inds = torch.empty((n, num_samples), dtype=torch.int64, device=bins.device) if want_inds else None
+    uu = None if u is None else f32c(u)
+    check(lib().dn_sample_pdf(ptr(bins), ptr(weights), ptr(uu), n, b, num_samples, ptr(samples),
+                              None if inds is None else c_void_p(inds.data_ptr()), stream()), "dn_sample_pdf")
+    return (samples, inds) if want_inds else samples
+
+
+def fine_depths(z_coarse, weights, num_fine, u=None, want_samples=False):
+    z_coarse, weights = f32c(z_coarse), f32c(weights)
+    n, nc = z_coarse.shape
+    z_fine = torch.empty((n, nc + num_fine), dtype=torch.float32, device=z_coarse.device)
+    zs = torch.empty((n, num_fine), dtype=torch.float32, device=z_coarse.device) if want_samples else None
+    uu = None if u is None else f32c(u)
+    check(lib().dn_fine_depths(ptr(z_coarse), ptr(weights), ptr(uu), n, nc, num_fine, ptr(z_fine), ptr(zs), stream()),
+          "dn_fine_depths")
+    return (z_fine, zs) if want_samples else z_fine
+
+
+_ws_cache = {}
+
+
+def render_rays(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, noise_std, white, m_thres, draws=None):
+    """dn_render_rays: the whole predict_and_render_radiance forward for one ray chunk (no autograd)."""
+    rays = f32c(rays)
+    n = rays.shape[0]
+    dev = rays.device
+    draws = draws or {}
+    k = len(m_thres)
+    fine = num_fine > 0 and packed_f is not None
+    nf = num_fine if fine else 0
+    nbytes = lib().dn_render_workspace_bytes(n, num_coarse, nf)
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = ws
+
+    def new(*shape):
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+    rgb_c, depth_c, acc_c = new(n, 3), new(n), new(n)
+    rgb_f, depth_f, acc_f = (new(n, 3), new(n), new(n)) if fine else (None, None, None)
+    dex = new(k, n) if k else None
+    prec = packed_c.precision
+    t = {name: (None if draws.get(name) is None else f32c(draws[name])) for name in ("t_rand", "noise_c", "u", "noise_f")}
+    check(lib().dn_render_rays(
+        ctypes.byref(packed_c.desc), ptr(packed_c.buffer),
+        ctypes.byref(packed_f.desc) if fine else None, ptr(packed_f.buffer) if fine else None, prec,
+        ptr(rays), rays.shape[1], n, num_coarse, nf, int(bool(lindisp)), float(noise_std), int(bool(white)),
+        host_floats(m_thres), k, ptr(t["t_rand"]), ptr(t["noise_c"]), ptr(t["u"]), ptr(t["noise_f"]),
+        ptr(rgb_c), ptr(depth_c), ptr(acc_c), ptr(rgb_f), ptr(depth_f), ptr(acc_f), ptr(dex), ptr(ws), stream()),
+        "dn_render_rays")
+    return rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f, dex

@@ -1,0 +1,216 @@
+"""run_network / predict_and_render_radiance / run_one_iter_of_nerf with the reference's call surface
+(reference nerf/train_utils.py:72-288), plus the Dex depth-error helpers (:9-70)."""
+import numpy as np
+import torch
+
+from . import _ops
+from ._train import run_network_fused
+from .models import FlexibleNeRFModel
+from .nerf_helpers import Embedder, _require_device, get_minibatches, ndc_rays
+from .nerf_helpers import sample_pdf_2 as sample_pdf  # noqa: F401  (reference train_utils.py:6 alias)
+from .volume_rendering_utils import _thresholds, volume_render_radiance_field
+
+
+# ---- Dex depth metrics (reference train_utils.py:9-70; validation-time logging, numpy/torch host code) ----
+def compute_err_metric(depth_gt, depth_pred, mask):
+    """Masked depth errors (reference :9-30): mean |err| in millimetres (inputs are metres) and the fraction
+    of masked pixels whose error exceeds 2 / 4 / 8 mm.  `mask` is a boolean selector."""
+    gt, pred = depth_gt[mask], depth_pred[mask]
+    diff = torch.abs(gt - pred)
+    count = diff.numel()
+    return {"depth_abs_err": torch.mean(torch.abs(pred * 1000 - gt * 1000)).item(),
+            "depth_err2": int((diff > 2e-3).sum()) / count,
+            "depth_err4": int((diff > 4e-3).sum()) / count,
+            "depth_err8": int((diff > 8e-3).sum()) / count}
+
+
+def gen_error_colormap_depth():
+    """Piecewise-constant blue->red colormap rows [lo, hi, r, g, b] (reference :31-48)."""
+    cols = np.array(
+        [[0, 0.00001, 0, 0, 0], [0.00001, 2000. / (2 ** 10), 49, 54, 149], [2000. / (2 ** 10), 2000. / (2 ** 9), 69, 117, 180],
+         [2000. / (2 ** 9), 2000. / (2 ** 8), 116, 173, 209], [2000. / (2 ** 8), 2000. / (2 ** 7), 171, 217, 233],
+         [2000. / (2 ** 7), 2000. / (2 ** 6), 224, 243, 248], [2000. / (2 ** 6), 2000. / (2 ** 5), 254, 224, 144],
+         [2000. / (2 ** 5), 2000. / (2 ** 4), 253, 174, 97], [2000. / (2 ** 4), 2000. / (2 ** 3), 244, 109, 67],
+         [2000. / (2 ** 3), 2000. / (2 ** 2), 215, 48, 39], [2000. / (2 ** 2), np.inf, 165, 0, 38]], dtype=np.float32)
+    cols[:, 2:5] /= 255.
+    return cols
+
+
+def depth_error_img(D_est_tensor, D_gt_tensor, mask, abs_thres=1., dilate_radius=1):
+    """Colour-coded |gt - est| / abs_thres image for logging: inputs (B, H, W), returns the first image
+    (H, W, 3) as numpy with the colour legend painted in its top-left corner (reference :46-70)."""
+    gt = D_gt_tensor.detach().cpu().numpy()
+    est = D_est_tensor.detach().cpu().numpy()
+    valid = mask.detach().cpu().numpy().astype(bool)
+    batch, height, width = gt.shape
+    err = np.abs(gt - est)
+    err[~valid] = 0
+    err[valid] = err[valid] / abs_thres
+    cols = gen_error_colormap_depth()
+    img = np.zeros([batch, height, width, 3], dtype=np.float32)
+    for row in cols:
+        img[np.logical_and(err >= row[0], err < row[1])] = row[2:]
+    img[~valid] = 0.
+    for i, row in enumerate(cols):  # legend: 20-pixel-wide swatches along the top edge
+        img[:, :10, i * 20:(i + 1) * 20, :] = row[2:]
+    return img[0]
+
+
+# ---- hot path ------------------------------------------------------------------------------------------
+def _fusable(network_fn, embed_fn, embeddirs_fn):
+    if not (isinstance(network_fn, FlexibleNeRFModel) and network_fn.fused_ok()):
+        return False
+    if not isinstance(embed_fn, Embedder):
+        return False
+    if embed_fn.num_encoding_functions != network_fn.num_encoding_fn_xyz or not embed_fn.include_input:
+        return False
+    if network_fn.use_viewdirs:
+        if not isinstance(embeddirs_fn, Embedder):
+            return False
+        if embeddirs_fn.num_encoding_functions != network_fn.num_encoding_fn_dir or not embeddirs_fn.include_input:
+            return False
+    return True
+
+
+def run_network(network_fn, pts, ray_batch, chunksize, embed_fn, embeddirs_fn):
+    """Embed points (+ per-ray view directions) and evaluate the network: (..., S, 3) -> (..., S, 4)
+    (reference train_utils.py:72-89).  A FlexibleNeRFModel with this package's embedders runs as one fused
+    HIP kernel (encoding never materialised); any other callable gets the generic composition:
+    HIP encoding -> network_fn minibatches -> concat."""
+    _require_device(pts, "run_network")
+    if _fusable(network_fn, embed_fn, embeddirs_fn):
+        s = pts.shape[-2] if pts.dim() >= 2 else 1
+        viewdirs = ray_batch[..., -3:] if network_fn.use_viewdirs else None
+        log_dir = embeddirs_fn.log_sampling if network_fn.use_viewdirs else True
+        out = run_network_fused(network_fn, pts, viewdirs, s, embed_fn.log_sampling, log_dir)
+        return out.reshape(list(pts.shape[:-1]) + [4])
+    pts_flat = pts.reshape((-1, pts.shape[-1]))
+    embedded = embed_fn(pts_flat)
+    if embeddirs_fn is not None:
+        viewdirs = ray_batch[..., None, -3:]
+        input_dirs = viewdirs.expand(pts.shape).reshape((-1, 3))
+        embedded = torch.cat((embedded, embeddirs_fn(input_dirs)), dim=-1)
+    preds = [network_fn(batch) for batch in get_minibatches(embedded, chunksize=chunksize)]
+    radiance_field = torch.cat(preds, dim=0)
+    return radiance_field.reshape(list(pts.shape[:-1]) + [radiance_field.shape[-1]])
+
+
+def _wants_grad(*models):
+    if not torch.is_grad_enabled():
+        return False
+    return any(m is not None and isinstance(m, torch.nn.Module) and any(p.requires_grad for p in m.parameters())
+               for m in models)
+
+
+def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mode="train",
+                                encode_position_fn=None, encode_direction_fn=None, m_thres_cand=None):
+    """One ray chunk through coarse sampling -> coarse net -> composite -> inverse-CDF resampling -> fine
+    net -> composite (reference train_utils.py:92-202).
+
+    Returns (rgb_coarse, depth_coarse, acc_coarse, rgb_fine, depth_fine, acc_fine, *depth_fine_dex[K]).
+    Supersets of the fork: m_thres_cand=None gives exactly six outputs (eval_nerf.py:175-187 unpacks six);
+    num_fine == 0 / model_fine None returns None for the fine maps and the coarse Dex depths instead of the
+    fork's NameError (:201).  RNG draw order matches the reference (rand, randn, rand, randn).
+    """
+    _require_device(ray_batch, "predict_and_render_radiance")
+    opt = getattr(options.nerf, mode)
+    thres = _thresholds(m_thres_cand)
+    n = ray_batch.shape[0]
+    nc, nf = int(opt.num_coarse), int(opt.num_fine)
+    fine = nf > 0 and model_fine is not None
+    perturb = bool(opt.perturb)
+    std = float(opt.radiance_field_noise_std)
+    white = bool(opt.white_background)
+    lindisp = bool(opt.lindisp)
+    dev = ray_batch.device
+    use_viewdirs = ray_batch.shape[-1] > 8
+
+    def rand(*shape):
+        return torch.rand(shape, dtype=torch.float32, device=dev)
+
+    def randn(*shape):
+        return torch.randn(shape, dtype=torch.float32, device=dev)
+
+    fused_models = (_fusable(model_coarse, encode_position_fn, encode_direction_fn)
+                    and (not fine or _fusable(model_fine, encode_position_fn, encode_direction_fn))
+                    and model_coarse.use_viewdirs == use_viewdirs)
+    if fused_models and not _wants_grad(model_coarse, model_fine):
+        # whole chunk in one C-ABI call (dn_render_rays); draws generated in the reference's order
+        draws = {}
+        if perturb:
+            draws["t_rand"] = rand(n, nc)
+        if std > 0.0:
+            draws["noise_c"] = randn(n, nc)
+        if fine and perturb:
+            draws["u"] = rand(n, nf)
+        if fine and std > 0.0:
+            draws["noise_f"] = randn(n, nc + nf)
+        lx = encode_position_fn.log_sampling
+        ld = encode_direction_fn.log_sampling if use_viewdirs else True
+        pc = model_coarse.packed(lx, ld)
+        pf = model_fine.packed(lx, ld) if fine else None
+        rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f, dex = _ops.render_rays(
+            pc, pf, ray_batch, nc, nf if fine else 0, lindisp, std, white, thres, draws)
+        dex_list = [] if dex is None else [dex[k] for k in range(dex.shape[0])]
+        return tuple([rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f] + dex_list)
+
+    # stage-by-stage composition (training / autograd, or a network the fused kernel does not cover)
+    rays = _ops.f32c(ray_batch)
+    ro, rd = rays[..., :3], rays[..., 3:6]
+    z_vals = _ops.coarse_depths(rays, nc, lindisp, rand(n, nc) if perturb else None)
+    pts = ro[..., None, :] + rd[..., None, :] * z_vals[..., :, None]
+    rf = run_network(model_coarse, pts, rays, opt.chunksize, encode_position_fn, encode_direction_fn)
+    coarse = volume_render_radiance_field(rf, z_vals, rd, radiance_field_noise_std=std, white_background=white,
+                                          m_thres_cand=thres)
+    rgb_c, acc_c, weights, depth_c = coarse[0], coarse[2], coarse[3], coarse[4]
+    if not fine:
+        return tuple([rgb_c, depth_c, acc_c, None, None, None] + list(coarse[5:]))
+    u = rand(n, nf) if perturb else None
+    z_fine = _ops.fine_depths(z_vals, weights.detach(), nf, u)
+    pts = ro[..., None, :] + rd[..., None, :] * z_fine[..., :, None]
+    rf = run_network(model_fine, pts, rays, opt.chunksize, encode_position_fn, encode_direction_fn)
+    fine_out = volume_render_radiance_field(rf, z_fine, rd, radiance_field_noise_std=std, white_background=white,
+                                            m_thres_cand=thres)
+    return tuple([rgb_c, depth_c, acc_c, fine_out[0], fine_out[4], fine_out[2]] + list(fine_out[5:]))
+
+
+def run_one_iter_of_nerf(height, width, focal_length, model_coarse, model_fine, ray_origins, ray_directions, options,
+                         mode="train", encode_position_fn=None, encode_direction_fn=None, m_thres_cand=None):
+    """Pack rays, chunk, render, concatenate (reference train_utils.py:205-288).
+
+    Output order: rgb_coarse, depth_coarse, acc_coarse, rgb_fine, depth_fine, acc_fine, *dex_fine[K]; flat
+    (N,3)/(N,) in train mode, reshaped to the image in validation mode (slots 1/4 are depth, not disparity).
+    """
+    _require_device(ray_directions, "run_one_iter_of_nerf")
+    thres = _thresholds(m_thres_cand)
+    viewdirs = None
+    if options.nerf.use_viewdirs:
+        viewdirs = ray_directions / ray_directions.norm(p=2, dim=-1).unsqueeze(-1)
+        viewdirs = viewdirs.reshape((-1, 3))
+    img_shape = ray_directions.shape
+    restore_shapes = [img_shape, img_shape[:-1], img_shape[:-1]]
+    if model_fine:
+        restore_shapes = restore_shapes + restore_shapes
+    restore_shapes = restore_shapes + [img_shape[:-1]] * len(thres)
+    if options.dataset.no_ndc is False:
+        ro, rd = ndc_rays(height, width, focal_length, 1.0, ray_origins, ray_directions)
+    else:
+        ro, rd = ray_origins, ray_directions
+    ro, rd = ro.reshape((-1, 3)), rd.reshape((-1, 3))
+    near = options.dataset.near * torch.ones_like(rd[..., :1])
+    far = options.dataset.far * torch.ones_like(rd[..., :1])
+    parts = [ro, rd, near, far] + ([viewdirs] if viewdirs is not None else [])
+    rays = torch.cat(parts, dim=-1).float()
+    chunks = [predict_and_render_radiance(batch, model_coarse, model_fine, options, mode=mode,
+                                          encode_position_fn=encode_position_fn,
+                                          encode_direction_fn=encode_direction_fn, m_thres_cand=thres)
+              for batch in get_minibatches(rays, chunksize=getattr(options.nerf, mode).chunksize)]
+    images = [torch.cat(col, dim=0) if col[0] is not None else None for col in zip(*chunks)]
+    if mode == "validation":
+        if not model_fine:
+            # coarse-only: rgb, depth, acc, (None x3), dex...  -> reference returns the 3 maps + three Nones
+            shapes = restore_shapes[:3] + [None, None, None] + restore_shapes[3:]
+        else:
+            shapes = restore_shapes
+        images = [img.reshape(shape) if img is not None else None for img, shape in zip(images, shapes)]
+    return tuple(images)

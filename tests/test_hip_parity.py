@@ -1,0 +1,323 @@
+"""GPU parity tests: the HIP path (through the C ABI, via nerf._ops / the drop-in call surface) against
+golden vectors captured from the reference and against the CPU oracle.
+
+Tolerances: index / integer work bit-exact; floating point
+`max|a-b| <= 1e-4 * max|b|` per output tensor in fp32 mode; bf16 mode is judged on PSNR.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from golden_cases import CASES, M_THRES, draws_of
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    import nerf
+    from nerf import _hip
+    _hip.lib()  # must load: no fallback
+    nerf.set_precision("fp32")
+    return torch.device("cuda:0")
+
+
+def G(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def C(t):
+    return t.detach().cpu().numpy()
+
+
+def make_models(mkw, sd_c, sd_f, dev):
+    import nerf
+    out = []
+    for sd in (sd_c, sd_f):
+        m = nerf.models.FlexibleNeRFModel(**mkw)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        out.append(m.to(dev))
+    return out
+
+
+def make_cfg(rkw, chunksize=4096):
+    import nerf
+    mode = dict(chunksize=chunksize, lindisp=rkw.get("lindisp", False), num_coarse=rkw["num_coarse"],
+                num_fine=rkw["num_fine"], perturb=rkw.get("perturb", False),
+                radiance_field_noise_std=rkw.get("noise_std", 0.0), white_background=rkw.get("white_background", False))
+    return nerf.CfgNode(dict(dataset=dict(near=rkw["near"], far=rkw["far"], no_ndc=True),
+                             nerf=dict(use_viewdirs=True, train=dict(mode), validation=dict(mode))))
+
+
+# ------------------------------------------------------------------------------------------------
+def test_ray_bundle(golden, dev):
+    import nerf
+    g = golden("kat")
+    for tag, h, w in (("rb0", 3, 4), ("rb1", 20, 30)):
+        ro, rd = nerf.get_ray_bundle(h, w, 1.0, G(g[tag + "_E"], dev), G(g[tag + "_K"], dev))
+        np.testing.assert_array_equal(C(ro), g[tag + "_ro"])
+        np.testing.assert_array_equal(C(rd), g[tag + "_rd"])
+
+
+def test_coarse_depths_bit_exact(golden, dev):
+    from nerf import _ops
+    from oracle import nerf_oracle as oc
+    for name in ("render_d8w256_val", "render_d8w256_lindisp", "train_d8w256", "train_lego"):
+        g = golden(name)
+        rkw = CASES[name][2]
+        cfg = oc.RenderCfg(**{k: v for k, v in rkw.items()})
+        rays = oc.pack_rays(torch.from_numpy(g["ro"]), torch.from_numpy(g["rd"]), cfg)
+        t_rand = G(g["draw_rand0"], dev) if "draw_rand0" in g else None
+        z = _ops.coarse_depths(rays.to(dev), rkw["num_coarse"], rkw.get("lindisp", False), t_rand)
+        np.testing.assert_array_equal(C(z), g["z_coarse"])
+
+
+def test_positional_encoding(golden, dev):
+    import nerf
+    g = golden("kat")
+    x = G(g["pe_x"], dev)
+    cases = (("pe_l10", dict(num_encoding_functions=10)), ("pe_l4", dict(num_encoding_functions=4)),
+             ("pe_l6_lin", dict(num_encoding_functions=6, log_sampling=False)),
+             ("pe_l4_noinput", dict(num_encoding_functions=4, include_input=False)),
+             ("pe_l0", dict(num_encoding_functions=0)))
+    for name, kw in cases:
+        out = C(nerf.positional_encoding(x, **kw))
+        assert out.shape == g[name].shape
+        assert np.abs(out - g[name]).max() < 2e-6, name  # sin/cos agree to ~1 ulp of 1.0
+    e = nerf.get_embedding_function(10, True, True)
+    assert np.abs(C(e(x)) - g["pe_l10"]).max() < 2e-6
+
+
+@pytest.mark.parametrize("tag", ["sp1", "sp2", "sp3"])
+def test_sampler_bit_exact(golden, dev, tag):
+    from nerf import _ops
+    g = golden("kat")
+    nf = g[tag + "_det"].shape[1]
+    s, inds = _ops.sample_pdf(G(g[tag + "_bins"], dev), G(g[tag + "_w"], dev), nf, None, want_inds=True)
+    np.testing.assert_array_equal(C(inds), g[tag + "_det_inds"])
+    np.testing.assert_array_equal(C(s), g[tag + "_det"])
+    s, inds = _ops.sample_pdf(G(g[tag + "_bins"], dev), G(g[tag + "_w"], dev), nf, G(g[tag + "_u"], dev), want_inds=True)
+    np.testing.assert_array_equal(C(inds), g[tag + "_rnd_inds"])
+    np.testing.assert_array_equal(C(s), g[tag + "_rnd"])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_sampler_boundary_on_render_goldens(golden, dev, name):
+    """Golden (bins, weights, u) -> indices bit-exact at the sampler boundary; merged depths bit-exact."""
+    from nerf import _ops
+    g = golden(name)
+    nf = g["sp_u"].shape[1]
+    u = G(g["sp_u"], dev) if "draw_rand1" in g else None
+    s, inds = _ops.sample_pdf(G(g["sp_bins"], dev), G(g["sp_weights"], dev), nf, u, want_inds=True)
+    np.testing.assert_array_equal(C(inds), g["sp_inds"])
+    np.testing.assert_array_equal(C(s), g["sp_z_samples"])
+    z_fine, zs = _ops.fine_depths(G(g["z_coarse"], dev), G(g["vc_weights"], dev), nf, u, want_samples=True)
+    np.testing.assert_array_equal(C(zs), g["sp_z_samples"])
+    np.testing.assert_array_equal(C(z_fine), g["z_fine"])
+
+
+def test_volume_render_kat(golden, dev):
+    import nerf
+    g = golden("kat")
+    out = nerf.volume_render_radiance_field(G(g["vr0_rf"], dev), G(g["vr0_z"], dev), G(g["vr0_rd"], dev),
+                                            m_thres_cand=[5.0, 10.0])
+    assert len(out) == 7
+    for n, o in zip(["rgb", "disp", "acc", "weights", "depth"], out[:5]):
+        assert rel_err(C(o), g["vr0_" + n]) < 1e-6, n
+    np.testing.assert_array_equal(C(out[5]), g["vr0_dex5"])
+    np.testing.assert_array_equal(C(out[6]), g["vr0_dex10"])
+    # m_thres_cand=None -> exactly 5 outputs (superset of the fork, which raises)
+    assert len(nerf.volume_render_radiance_field(G(g["vr0_rf"], dev), G(g["vr0_z"], dev), G(g["vr0_rd"], dev))) == 5
+
+
+@pytest.mark.parametrize("tag,std,white", [("a", 0.0, False), ("b", 0.0, True), ("c", 0.2, True)])
+def test_volume_render_random(golden, dev, tag, std, white):
+    from nerf import _ops
+    g = golden("kat")
+    rgb, disp, acc, weights, depth, dex = _ops.volume_render_fwd(
+        G(g["vr1_rf"], dev), G(g["vr1_z"], dev), G(g["vr1_rd"], dev), G(g["vr1_noise"], dev), std, white, list(M_THRES))
+    for n, o in zip(["rgb", "disp", "acc", "weights", "depth"], (rgb, disp, acc, weights, depth)):
+        assert rel_err(C(o), g[f"vr1{tag}_{n}"]) < 1e-5, n  # includes the NaN-disparity rows (acc == 0)
+    np.testing.assert_array_equal(C(dex), g[f"vr1{tag}_dex"])  # Dex depth exact given sigma
+
+
+def test_volume_render_backward_matches_autograd_of_oracle(golden, dev):
+    from nerf import _ops
+    from oracle import nerf_oracle as oc
+    g = golden("kat")
+    rng = np.random.default_rng(5)
+    for std, white in ((0.0, False), (0.2, True)):
+        rf = torch.from_numpy(g["vr1_rf"]).clone().requires_grad_(True)
+        z, rd, noise = (torch.from_numpy(g[k]) for k in ("vr1_z", "vr1_rd", "vr1_noise"))
+        v = oc.volume_render(rf, z, rd, noise, std, white, ())
+        n, s = z.shape
+        g_rgb = torch.from_numpy(rng.normal(size=(n, 3)).astype(np.float32))
+        g_depth = torch.from_numpy(rng.normal(size=(n,)).astype(np.float32))
+        g_acc = torch.from_numpy(rng.normal(size=(n,)).astype(np.float32))
+        g_w = torch.from_numpy(rng.normal(size=(n, s)).astype(np.float32))
+        loss = (v["rgb"] * g_rgb).sum() + (v["depth"] * g_depth).sum() + (v["acc"] * g_acc).sum() + (v["weights"] * g_w).sum()
+        loss.backward()
+        rfd = G(g["vr1_rf"], dev).requires_grad_(True)
+        out = _ops.VolumeRenderFn.apply(rfd, G(g["vr1_z"], dev), G(g["vr1_rd"], dev), G(g["vr1_noise"], dev), std, white, [])
+        lossd = ((out[0] * g_rgb.to(dev)).sum() + (out[4] * g_depth.to(dev)).sum() + (out[2] * g_acc.to(dev)).sum()
+                 + (out[3] * g_w.to(dev)).sum())
+        lossd.backward()
+        assert rel_err(C(rfd.grad), rf.grad.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("tag,kw", [("mlp_d4w128", dict(num_layers=4, hidden_size=128)),
+                                    ("mlp_d8w256", dict(num_layers=8, hidden_size=256)),
+                                    ("mlp_d8w256_noview", dict(num_layers=8, hidden_size=256, use_viewdirs=False))])
+def test_mlp_forward_encoded(golden, dev, tag, kw):
+    import nerf
+    from nerf import synthetic as syn
+    g = golden("kat")
+    full = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4,
+                use_viewdirs=True)
+    full.update(kw)
+    m = nerf.models.FlexibleNeRFModel(**full)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(11, **full).items()})
+    m = m.to(dev)
+    x = g["mlp_in"]
+    x = x[:, : m.dim_xyz + m.dim_dir]
+    with torch.no_grad():
+        out = m(G(x, dev))
+    assert rel_err(C(out), g[tag]) < 1e-5
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_run_network_on_golden_points(golden, dev, name):
+    import nerf
+    g = golden(name)
+    mkw, wfn, rkw = CASES[name]
+    mc, mf = make_models(mkw, *wfn(), dev)
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    rd = torch.from_numpy(g["rd"])
+    vd = (rd / rd.norm(p=2, dim=-1).unsqueeze(-1)).to(dev)
+    rays = torch.cat([G(g["ro"], dev), G(g["rd"], dev), torch.zeros(len(rd), 2, device=dev), vd], -1)
+    with torch.no_grad():
+        rf_c = nerf.run_network(mc, G(g["pts_coarse"], dev), rays, 4096, ex, ed)
+        rf_f = nerf.run_network(mf, G(g["pts_fine"], dev), rays, 4096, ex, ed)
+    assert rel_err(C(rf_c), g["rf_coarse"]) < TOL
+    assert rel_err(C(rf_f), g["rf_fine"]) < TOL
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_render_goldens_end_to_end(golden, dev, name, monkeypatch):
+    """predict_and_render_radiance (one dn_render_rays call) on the golden rays/weights with the reference's
+    recorded RNG draws injected through torch.rand / torch.randn."""
+    import nerf
+    g = golden(name)
+    mkw, wfn, rkw = CASES[name]
+    mc, mf = make_models(mkw, *wfn(), dev)
+    cfg = make_cfg(rkw)
+    draws = draws_of(g)
+    if draws is not None:
+        q_rand = [G(draws["t_rand"], dev), G(draws["u"], dev)]
+        q_randn = [G(draws["noise_c"], dev), G(draws["noise_f"], dev)]
+        monkeypatch.setattr(torch, "rand", lambda *a, **k: q_rand.pop(0))
+        monkeypatch.setattr(torch, "randn", lambda *a, **k: q_randn.pop(0))
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    with torch.no_grad():
+        out = nerf.run_one_iter_of_nerf(1, len(g["ro"]), 1.0, mc, mf, G(g["ro"], dev)[None], G(g["rd"], dev)[None], cfg,
+                                        mode="validation", encode_position_fn=ex, encode_direction_fn=ed,
+                                        m_thres_cand=np.arange(5, 105, 5))
+    assert len(out) == 6 + len(M_THRES)
+    names = ["rgb_coarse", "depth_coarse", "acc_coarse", "rgb_fine", "depth_fine", "acc_fine"]
+    for n, o in zip(names, out[:6]):
+        ref = g["out_" + n]
+        assert o.shape[:2] == (1, len(g["ro"]))
+        assert rel_err(C(o).reshape(ref.shape), ref) < TOL, n
+    dex = np.stack([C(o).reshape(-1) for o in out[6:]])
+    assert (dex == g["out_dex_fine"]).mean() > 0.995  # argmax over a thresholded signal: ulp flips allowed
+    out6 = nerf.run_one_iter_of_nerf(1, 8, 1.0, mc, mf, G(g["ro"][:8], dev)[None], G(g["rd"][:8], dev)[None],
+                                     make_cfg({**rkw, "perturb": False, "noise_std": 0.0}), mode="validation",
+                                     encode_position_fn=ex, encode_direction_fn=ed) if draws is None else None
+    if out6 is not None:
+        assert len(out6) == 6  # m_thres_cand=None: exactly six outputs (eval_nerf.py:175-187)
+
+
+def test_bf16_mode_psnr(golden, dev):
+    """Throughput mode: bf16 MFMA with fp32 accumulation, judged on PSNR against the fp32 reference outputs."""
+    import nerf
+    name = "render_lego_val"
+    g = golden(name)
+    mkw, wfn, rkw = CASES[name]
+    mc, mf = make_models(mkw, *wfn(), dev)
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    nerf.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            out = nerf.run_one_iter_of_nerf(1, len(g["ro"]), 1.0, mc, mf, G(g["ro"], dev)[None], G(g["rd"], dev)[None],
+                                            make_cfg(rkw), mode="validation", encode_position_fn=ex,
+                                            encode_direction_fn=ed, m_thres_cand=list(M_THRES))
+    finally:
+        nerf.set_precision("fp32")
+    mse = float(np.mean((C(out[3]).reshape(-1, 3) - g["out_rgb_fine"]) ** 2))
+    psnr = -10.0 * np.log10(max(mse, 1e-12))
+    print(f"bf16 vs reference rgb_fine PSNR {psnr:.1f} dB")
+    assert psnr > 35.0
+
+
+def test_large_render_properties_and_oracle(dev):
+    """C2-shaped workload (D8/W256, 64+128) at a size the oracle still finishes in seconds, plus
+    size-independent properties: determinism, chunk invariance, sorted merged depths, acc == sum(weights)."""
+    import nerf
+    from nerf import _ops, synthetic as syn
+    from oracle import nerf_oracle as oc
+    kw = CASES["render_d8w256_val"][0]
+    sd_c, sd_f = CASES["render_d8w256_val"][1]()
+    mc, mf = make_models(kw, sd_c, sd_f, dev)
+    h = w = 400
+    e_mat, k_mat = torch.from_numpy(syn.scene_pose(11)), torch.from_numpy(syn.intrinsic(h, w))
+    ro, rd = nerf.get_ray_bundle(h, w, float(k_mat[0, 0]), e_mat.to(dev), k_mat.to(dev))
+    sel = torch.from_numpy(syn.select_rays(h, w, 1536, seed=9)).to(dev)
+    ro, rd = ro.reshape(-1, 3)[sel].contiguous(), rd.reshape(-1, 3)[sel].contiguous()
+    rkw = dict(num_coarse=64, num_fine=128, near=2.0, far=6.0)
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    with torch.no_grad():
+        a = nerf.run_one_iter_of_nerf(h, w, 1.0, mc, mf, ro, rd, make_cfg(rkw, 4096), mode="train", encode_position_fn=ex,
+                                      encode_direction_fn=ed, m_thres_cand=list(M_THRES))
+        b = nerf.run_one_iter_of_nerf(h, w, 1.0, mc, mf, ro, rd, make_cfg(rkw, 500), mode="train", encode_position_fn=ex,
+                                      encode_direction_fn=ed, m_thres_cand=list(M_THRES))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)  # chunking (500-ray chunks, ragged tail) does not change a single bit
+    cfg_o = oc.RenderCfg(chunksize=4096, m_thres=M_THRES, **rkw)
+    mcfg = oc.ModelCfg(**kw)
+    with torch.no_grad():
+        ref = oc.run_one_iter(ro.cpu(), rd.cpu(), oc.to_torch_sd(sd_c), oc.to_torch_sd(sd_f), mcfg, mcfg, cfg_o)
+    for i in range(6):
+        assert rel_err(C(a[i]), ref[i].numpy()) < TOL, i
+    dex = np.stack([C(o) for o in a[6:]])
+    dex_ref = np.stack([o.numpy() for o in ref[6:]])
+    assert (dex == dex_ref).mean() > 0.995
+    # stage properties
+    rays = oc.pack_rays(ro.cpu(), rd.cpu(), cfg_o).to(dev)
+    z_c = _ops.coarse_depths(rays, 64, False, None)
+    rf = _ops.run_network_rays(mc.packed(), rays, z_c)
+    rgb, disp, acc, wts, depth, _ = _ops.volume_render_fwd(rf, z_c, rays[:, 3:6], None, 0.0, False, [])
+    assert rel_err(C(wts.sum(-1)), C(acc)) < 1e-5
+    assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
+    z_f = _ops.fine_depths(z_c, wts, 128, None)
+    assert bool((z_f[:, 1:] >= z_f[:, :-1]).all())
+    merged = torch.sort(torch.cat([z_c, _ops.sample_pdf(0.5 * (z_c[:, 1:] + z_c[:, :-1]), wts[:, 1:-1], 128)], -1), -1)[0]
+    assert torch.equal(merged, z_f)
+
+
+def test_host_tensors_and_bad_configs_fail_loudly(dev):
+    import nerf
+    with pytest.raises(RuntimeError):
+        nerf.volume_render_radiance_field(torch.zeros(2, 4, 4), torch.zeros(2, 4), torch.zeros(2, 3))
+    with pytest.raises(RuntimeError):
+        nerf.sample_pdf(torch.zeros(2, 16), torch.zeros(2, 15), 8, det=True)
+    from nerf import _ops
+    with pytest.raises(RuntimeError):
+        _ops.PackedMLP(dict(num_layers=8, hidden_size=192, skip_connect_every=4, num_encoding_fn_xyz=10,
+                            num_encoding_fn_dir=4, include_input_xyz=1, include_input_dir=1, use_viewdirs=1,
+                            log_sampling_xyz=1, log_sampling_dir=1), dev)
+    with pytest.raises(RuntimeError):
+        _ops.sample_pdf(torch.zeros(2, 4, device=dev), torch.zeros(2, 3, device=dev), 8)  # row too short

@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/s of the nerf-pytorch / Dex-NeRF ray-marching hot path on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): a 400x400 synthetic Lego-style view,
+64 coarse + 128 fine samples per ray, coarse and fine FlexibleNeRFModel D=8 / W=256 / skip 4 with view
+directions, PE L=10/4, K=20 Dex thresholds, validation-mode render (deterministic resampling, no noise).
+One "step" = one full image (160,000 rays) through run_one_iter_of_nerf -> predict_and_render_radiance on
+this rank's GPU, inputs (ray bundle, packed weights) resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+Multi-GPU: rays/images are independent units -> each rank renders its own view of the scene (weak scaling,
+no data-path collective); the barrier + max-over-ranks timing uses RCCL.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "dex-nerf_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+H = W = 400
+NC, NF = 64, 128
+MODEL_KW = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4,
+                use_viewdirs=True)
+FLOP_PER_POINT = 1186816           # unpadded dims, SURVEY.md section 8d
+POINTS_PER_RAY = NC + (NC + NF)    # coarse net + fine net
+M_THRES = [float(m) for m in range(5, 105, 5)]
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def build_scene(dev, rank):
+    import nerf
+    from nerf import synthetic as syn
+    models = []
+    for seed, bias in ((42, -150.0), (43, -20.0)):
+        m = nerf.models.FlexibleNeRFModel(**MODEL_KW)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(seed, sigma_bias=bias, **MODEL_KW).items()})
+        models.append(m.to(dev))
+    mode = dict(chunksize=H * W, lindisp=False, num_coarse=NC, num_fine=NF, perturb=False,
+                radiance_field_noise_std=0.0, white_background=False)
+    cfg = nerf.CfgNode(dict(dataset=dict(near=2.0, far=6.0, no_ndc=True),
+                            nerf=dict(use_viewdirs=True, train=dict(mode), validation=dict(mode))))
+    k_mat = torch.from_numpy(syn.intrinsic(H, W)).to(dev)
+    e_mat = torch.from_numpy(syn.scene_pose(7 + rank)).to(dev)   # each rank: its own view of the scene
+    ro, rd = nerf.get_ray_bundle(H, W, float(k_mat[0, 0]), e_mat, k_mat)
+    ex, ed = nerf.get_embedding_function(10, True, True), nerf.get_embedding_function(4, True, True)
+    return models, cfg, ro, rd, ex, ed
+
+
+def render(models, cfg, ro, rd, ex, ed):
+    import nerf
+    with torch.no_grad():
+        return nerf.run_one_iter_of_nerf(H, W, 1.0, models[0], models[1], ro, rd, cfg, mode="validation",
+                                         encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=M_THRES)
+
+
+def time_dominant_kernel(models, ro, rd, precision, reps=5):
+    """HIP-event timing of the dominant kernel (fused PE+MLP on the fine network, 160,000 x 192 points) on the
+    stream it is launched on (PyTorch's current stream)."""
+    from nerf import _ops
+    dev = ro.device
+    rays = torch.cat([ro.reshape(-1, 3), rd.reshape(-1, 3), torch.full((H * W, 1), 2.0, device=dev),
+                      torch.full((H * W, 1), 6.0, device=dev),
+                      torch.nn.functional.normalize(rd.reshape(-1, 3), dim=-1)], -1).contiguous()
+    z = torch.sort(torch.rand(H * W, NC + NF, device=dev) * 4.0 + 2.0, -1)[0].contiguous()
+    packed = models[1].packed()
+    _ops.run_network_rays(packed, rays, z)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _ops.run_network_rays(packed, rays, z)
+        b.record()
+        b.synchronize()
+        times.append(a.elapsed_time(b) * 1e-3)
+    t = float(np.mean(times))
+    flops = H * W * (NC + NF) * FLOP_PER_POINT
+    return t, flops / t / 1e12
+
+
+def cpu_baseline(sample_rays=4096):
+    """The CPU oracle (a restatement of the reference's PyTorch path, pinned to goldens captured from the
+    reference) timed on this box's host cores on a bounded sample of the same workload."""
+    from nerf import synthetic as syn
+    from oracle import nerf_oracle as oc
+    # the GPU box gives one-GPU jobs a 16-CPU share: more threads than that only oversubscribes
+    threads = max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16))
+    torch.set_num_threads(threads)
+    sd_c = oc.to_torch_sd(syn.synth_state_dict(42, sigma_bias=-150.0, **MODEL_KW))
+    sd_f = oc.to_torch_sd(syn.synth_state_dict(43, sigma_bias=-20.0, **MODEL_KW))
+    ro, rd = oc.get_ray_bundle(H, W, syn.scene_pose(7), syn.intrinsic(H, W))
+    sel = syn.select_rays(H, W, sample_rays, seed=0)
+    ro, rd = ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]
+    cfg = oc.RenderCfg(num_coarse=NC, num_fine=NF, near=2.0, far=6.0, chunksize=4096, m_thres=M_THRES)
+    mc = oc.ModelCfg(**MODEL_KW)
+    with torch.no_grad():
+        oc.run_one_iter(ro[:512], rd[:512], sd_c, sd_f, mc, mc, cfg)  # warm-up
+        t0 = time.perf_counter()
+        out = oc.run_one_iter(ro, rd, sd_c, sd_f, mc, mc, cfg)
+        dt = time.perf_counter() - t0
+    return dict(value=sample_rays / dt, unit="rays/s", cores=threads, kind="port",
+                sample=f"{sample_rays} rays of the same 400x400 view, 64+128 samples, D8/W256 fp32, "
+                       f"torch {torch.__version__} CPU, {threads} threads, {dt:.1f} s"), sel, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import nerf
+    from nerf import _hip
+    _hip.lib()  # fail loudly if the HIP extension is missing
+    nerf.set_precision(args.precision)
+    models, cfg, ro, rd, ex, ed = build_scene(dev, rank)
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+    note(f"scene built: {H}x{W} rays, precision {args.precision}")
+    for i in range(max(args.warmup, 0)):
+        out = render(models, cfg, ro, rd, ex, ed)
+        torch.cuda.synchronize()
+        note(f"warmup {i} done")
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = render(models, cfg, ro, rd, ex, ed)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    rays_total = world * H * W * args.steps
+    value = rays_total / elapsed
+
+    note(f"timed region: {elapsed:.3f} s for {args.steps} steps")
+    result = None
+    if rank == 0:
+        kt, ktf = time_dominant_kernel(models, ro, rd, args.precision)
+        note(f"dominant kernel {kt * 1e3:.2f} ms = {ktf:.0f} TFLOP/s")
+        peak = PEAK_TFLOPS[args.precision]
+        whole_tf = value / world * POINTS_PER_RAY * FLOP_PER_POINT / 1e12
+        result = {
+            "metric": "rays/sec (64+128 samples) + PSNR vs ref, 400x400 scene", "value": value, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": "C2 render: 400x400 rays/step/GPU, 64 coarse + 128 fine samples, coarse+fine "
+                                   "FlexibleNeRFModel D8/W256/skip4 + viewdirs, PE L=10/4, 20 Dex thresholds, "
+                                   "validation mode (det. resampling, no noise)",
+                       "rays_per_step_per_gpu": H * W, "sharding": f"{world} ranks x own view (no collective in the path)"},
+            "roofline": {"bound": "mfma", "achieved": ktf, "peak": peak, "unit": "TFLOP/s", "frac": ktf / peak,
+                         "traffic": None, "kernel": "mlp_forward_kernel<256,10,4> (fine net, 160000x192 points)",
+                         "kernel_ms": kt * 1e3, "whole_path_tflops": whole_tf},
+        }
+        if not args.no_cpu_baseline:
+            cb, sel, ref = cpu_baseline()
+            result["cpu_baseline"] = cb
+            rgb = out[3].reshape(-1, 3)[torch.from_numpy(sel).to(dev)].cpu().numpy()
+            mse = float(np.mean((rgb - ref[3].numpy()) ** 2))
+            result["psnr_vs_oracle_db"] = float(-10.0 * np.log10(max(mse, 1e-12)))
+            result["gpu_over_cpu"] = value / world / cb["value"]
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

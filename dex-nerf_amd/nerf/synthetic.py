@@ -70,20 +70,35 @@ def flexible_param_shapes(num_layers=8, hidden_size=256, skip_connect_every=4,
     return out
 
 
-def synth_state_dict(seed, sigma_gain=60.0, sigma_bias=-90.0, gain=2.45, **model_kwargs):
+def synth_state_dict(seed, sigma_gain=200.0, sigma_bias=-20.0, gain=2.45, freq_damping=0.8, **model_kwargs):
     """Deterministic nn.Linear-shaped weights (numpy float32 dict, `name.weight` / `name.bias`).
 
     Uniform(-b, b) with b = gain/sqrt(fan_in) (PyTorch's default is gain=1); gain=sqrt(6) keeps the
-    activation variance constant through the ReLU layers so the field has structure, and the
-    density head is scaled/shifted (`sigma_gain`, `sigma_bias`) so raw sigma is mostly negative
-    (empty space) with peaks that cross the Dex thresholds (5..100) on many rays.
+    activation variance constant through the ReLU layers so the field has structure.  The weight columns
+    that read the positional encoding of frequency 2^f are damped by 2^(-freq_damping*f) - the spectral
+    decay a trained NeRF has - otherwise the random field is chaotic at the 2^9 band and an fp32 ulp in a
+    sample depth changes the rendered colour by percents (measured: fp32-vs-fp64 runs of the same
+    reference code differ by 5e-2 without damping, 1e-5 with it).  The density head is scaled/shifted
+    (`sigma_gain`, `sigma_bias`) so raw sigma is mostly negative (empty space) with peaks that cross the
+    Dex thresholds (5..100) on many rays.
     """
     rng = np.random.default_rng(seed)
     sd = {}
+    lx = model_kwargs.get("num_encoding_fn_xyz", 10)
+    dim_xyz = (3 if model_kwargs.get("include_input_xyz", True) else 0) + 6 * lx
+    off = dim_xyz - 6 * lx
+    damp = np.ones(dim_xyz, np.float32)
+    for f in range(lx):
+        damp[off + 6 * f: off + 6 * f + 6] = 2.0 ** (-freq_damping * f)
+    hidden = model_kwargs.get("hidden_size", 256)
     for name, (fan_out, fan_in) in flexible_param_shapes(**model_kwargs):
         b = gain / math.sqrt(fan_in)
         w = rng.uniform(-b, b, size=(fan_out, fan_in)).astype(np.float32)
         bias = rng.uniform(-b, b, size=(fan_out,)).astype(np.float32)
+        if name == "layer1":
+            w = (w * damp).astype(np.float32)
+        elif name.startswith("layers_xyz.") and fan_in == hidden + dim_xyz:
+            w[:, hidden:] = w[:, hidden:] * damp
         if name in ("fc_alpha",):
             w = (w * sigma_gain).astype(np.float32)
             bias = (bias * sigma_gain + sigma_bias).astype(np.float32)

@@ -360,12 +360,12 @@ def d8w256():
     """North-star nets: D=8, W=256, skip 4 (needs the harness alias), 64+128."""
     full = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10,
                 num_encoding_fn_dir=4, use_viewdirs=True)
-    mc = build_model(syn.synth_state_dict(42, sigma_bias=-70.0, **full), **full)
-    mf = build_model(syn.synth_state_dict(43, sigma_bias=-30.0, **full), **full)
+    mc = build_model(syn.synth_state_dict(42, sigma_bias=-150.0, **full), **full)
+    mf = build_model(syn.synth_state_dict(43, sigma_bias=-20.0, **full), **full)
     E, K, ro, rd, sel = rays_for(400, 400, 7, 192, seed=0)
     cfg = make_cfg(64, 128, 2.0, 6.0, perturb=False, noise_std=0.0, white=False)
     capture_render("render_d8w256_val", mc, mf, cfg, ro, rd, "validation", 10, 4,
-                   extra=dict(E=npf(E), K=npf(K), sel=sel, seed_c=42, seed_f=43, sigma_bias_c=-70.0, sigma_bias_f=-30.0))
+                   extra=dict(E=npf(E), K=npf(K), sel=sel, seed_c=42, seed_f=43, sigma_bias_c=-150.0, sigma_bias_f=-20.0))
     # lindisp + Dex-scene bounds (C3: near .3 far 4)
     cfg = make_cfg(64, 64, 0.3, 4.0, perturb=False, noise_std=0.0, white=False, lindisp=True)
     capture_render("render_d8w256_lindisp", mc, mf, cfg, ro[:64] * 0.25, rd[:64], "validation", 10, 4)

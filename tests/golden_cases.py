@@ -23,7 +23,7 @@ def lego_weights():
 
 
 def d8_weights():
-    return (syn.synth_state_dict(42, sigma_bias=-70.0, **D8), syn.synth_state_dict(43, sigma_bias=-30.0, **D8))
+    return (syn.synth_state_dict(42, sigma_bias=-150.0, **D8), syn.synth_state_dict(43, sigma_bias=-20.0, **D8))
 
 
 # name -> (model kwargs, weights fn, render settings)

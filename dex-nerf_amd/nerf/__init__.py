@@ -5,7 +5,7 @@ ray generation, stratified + hierarchical sampling, positional encoding, the coa
 alpha compositing with the Dex fixed-sigma depth readout all run in hand-written HIP kernels
 (libdexnerf_hip.so) whenever tensors live on the ROCm device.  Dataset loaders are out of scope.
 """
-from . import models  # noqa: F401  (scripts use getattr(models, cfg.models.coarse.type))
+from . import models, parallel, synthetic  # noqa: F401  (scripts use getattr(models, cfg.models.coarse.type))
 from ._ops import get_precision, set_precision  # noqa: F401
 from .cfgnode import CfgNode  # noqa: F401
 from .models import *  # noqa: F401,F403

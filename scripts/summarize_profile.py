@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Condense a rocprofv3 --kernel-trace --stats CSV directory into profiles/<tag>_*.csv/.md (kept in git).
+
+usage: scripts/summarize_profile.py gpurun_out/prof_r01/<host> r01
+"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+src, tag = sys.argv[1], sys.argv[2]
+repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_dir = os.path.join(repo, "profiles")
+os.makedirs(out_dir, exist_ok=True)
+stats = glob.glob(os.path.join(src, "*_kernel_stats.csv"))[0]
+trace = glob.glob(os.path.join(src, "*_kernel_trace.csv"))[0]
+rows = list(csv.DictReader(open(stats)))
+with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows:
+        w.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+groups = defaultdict(list)
+meta = {}
+for r in csv.DictReader(open(trace)):
+    name = r["Kernel_Name"]
+    if "dn::" not in name:
+        continue
+    dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    short = name.split("(")[0].replace("void ", "")
+    groups[short].append(dur)
+    meta[short] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"],
+                   r["Workgroup_Size_X"], r["Grid_Size_X"])
+lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
+         "Per-kernel launch durations of this repo's kernels (ns), from the kernel trace.  For the fused network",
+         "kernel the launches split into the coarse net (64 samples/ray) and the fine net (192 samples/ray);",
+         "bench.py's `roofline.kernel_ms` is the fine-net launch.", "",
+         "| kernel | calls | avg ns | min ns | max ns | VGPR | AGPR | SGPR | LDS B | scratch B | wg | grid |",
+         "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+for k, v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+    m = meta[k]
+    lines.append(f"| {k} | {len(v)} | {sum(v) / len(v):.0f} | {min(v)} | {max(v)} | " + " | ".join(m) + " |")
+    if "mlp_forward_kernel" in k and len(v) > 2:
+        cut = (min(v) + max(v)) / 2
+        small = [d for d in v if d < cut]
+        big = [d for d in v if d >= cut]
+        if small and big:
+            lines.append(f"| &nbsp;&nbsp;coarse-net launches | {len(small)} | {sum(small) / len(small):.0f} | {min(small)} | {max(small)} | | | | | | | |")
+            lines.append(f"| &nbsp;&nbsp;fine-net launches | {len(big)} | {sum(big) / len(big):.0f} | {min(big)} | {max(big)} | | | | | | | |")
+open(os.path.join(out_dir, f"{tag}_kernel_summary.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))

@@ -333,3 +333,46 @@ def test_host_tensors_and_bad_configs_fail_loudly(dev):
                             log_sampling_xyz=1, log_sampling_dir=1), dev)
     with pytest.raises(RuntimeError):
         _ops.sample_pdf(torch.zeros(2, 4, device=dev), torch.zeros(2, 3, device=dev), 8)  # row too short
+
+
+@pytest.mark.parametrize("name", ["train_lego", "train_d8w256"])
+def test_train_step_matches_reference(golden, dev, name, monkeypatch):
+    """One training iteration (perturbed sampling + density noise, the reference's recorded draws injected):
+    loss, parameter gradients of both nets and - for the lego nets - the parameters after one Adam step."""
+    import nerf
+    from conftest import load_golden
+    g = golden(name)
+    mkw, wfn, rkw = CASES[name]
+    mc, mf = make_models(mkw, *wfn(), dev)
+    cfg = make_cfg(rkw)
+    draws = draws_of(g)
+    q_rand = [G(draws["t_rand"], dev), G(draws["u"], dev)]
+    q_randn = [G(draws["noise_c"], dev), G(draws["noise_f"], dev)]
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: q_rand.pop(0))
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: q_randn.pop(0))
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    params = list(mc.parameters()) + list(mf.parameters())
+    opt = torch.optim.Adam(params, lr=5e-3)
+    out = nerf.run_one_iter_of_nerf(1, len(g["ro"]), 1.0, mc, mf, G(g["ro"], dev), G(g["rd"], dev), cfg, mode="train",
+                                    encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=list(M_THRES))
+    assert not q_rand and not q_randn  # all four draws consumed, in the reference's order
+    assert out[0].requires_grad and out[3].requires_grad and not out[6].requires_grad
+    target = G(g["target"], dev)
+    loss = nerf.img2mse(out[0][..., :3], target) + nerf.img2mse(out[3][..., :3], target)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    for pref, m in (("gc_", mc), ("gf_", mf)):
+        for k, p in m.named_parameters():
+            gr = C(p.grad)
+            if pref + k in g:
+                assert rel_err(gr, g[pref + k]) < 1e-3, k
+            else:
+                assert rel_err(gr.reshape(-1)[::97], g[pref + k + ".sub"]) < 1e-3, k
+                nrm = float(g[pref + k + ".norm"])
+                assert abs(np.linalg.norm(gr.astype(np.float64)) - nrm) < 1e-3 * nrm, k
+    if name == "train_lego":
+        opt.step()
+        post = load_golden("train_lego_post_adam")
+        for pref, m in (("pc_", mc), ("pf_", mf)):
+            for k, p in m.state_dict().items():
+                assert rel_err(C(p), post[pref + k]) < 2e-3, k

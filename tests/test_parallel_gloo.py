@@ -1,0 +1,97 @@
+"""World-size-2 checks of the data-parallel helpers on CPU (gloo): ray-row sharding + all_gather of rendered
+maps, and the single flat-bucket gradient all-reduce that keeps replicas in lock-step."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, fn_name, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "dex-nerf_amd"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        globals()[fn_name](rank, world, tmp)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn_name, tmp_path, world=2):
+    mp.spawn(_worker, args=(world, _free_port(), fn_name, str(tmp_path)), nprocs=world, join=True)
+
+
+def _case_render_sharded(rank, world, tmp):
+    from nerf import parallel
+    h, w = 7, 5  # odd height: ragged blocks
+    ro = torch.arange(h * w * 3, dtype=torch.float32).reshape(h, w, 3)
+    rd = ro + 0.5
+
+    def fake_render(ro_b, rd_b):
+        return (ro_b * 2.0 + rd_b, ro_b[..., 0] - rd_b[..., 1], None)
+    out = parallel.render_sharded(fake_render, ro, rd)
+    assert out[2] is None
+    assert torch.equal(out[0], ro * 2.0 + rd) and torch.equal(out[1], ro[..., 0] - rd[..., 1])
+    lo, hi = parallel.shard_bounds(h, rank, world)
+    assert (lo, hi) == ((0, 4) if rank == 0 else (4, 7))
+
+
+def _case_flat_bucket(rank, world, tmp):
+    from nerf import models, parallel
+    torch.manual_seed(100 + rank)  # different init per rank on purpose
+    coarse = models.FlexibleNeRFModel(num_layers=3, hidden_size=32)
+    fine = models.FlexibleNeRFModel(num_layers=3, hidden_size=32)
+    parallel.broadcast_parameters([coarse, fine], src=0)
+    bucket = parallel.FlatGradBucket([coarse, fine])
+    n_params = sum(p.numel() for m in (coarse, fine) for p in m.parameters())
+    assert bucket.flat.numel() == n_params
+    opt = torch.optim.Adam(bucket.params, lr=1e-2)
+    torch.manual_seed(7 + rank)  # each rank: its own rays
+    for step in range(3):
+        x = torch.randn(16, coarse.dim_xyz + coarse.dim_dir)
+        bucket.zero()
+        loss = coarse(x).pow(2).mean() + fine(x).pow(2).mean()
+        loss.backward()
+        assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in bucket.params)  # grads still views of the bucket
+        local = bucket.flat.clone()
+        bucket.all_reduce_mean()
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        assert torch.allclose(bucket.flat, sum(gathered) / world, atol=1e-7)
+        opt.step()
+    flat_w = torch.cat([p.detach().reshape(-1) for p in bucket.params])
+    gathered = [torch.empty_like(flat_w) for _ in range(world)]
+    dist.all_gather(gathered, flat_w)
+    assert torch.equal(gathered[0], gathered[1])  # replicas stayed bit-identical
+
+
+def test_render_sharded_world2(tmp_path):
+    _run("_case_render_sharded", tmp_path)
+
+
+def test_flat_grad_bucket_world2(tmp_path):
+    _run("_case_flat_bucket", tmp_path)
+
+
+def test_shard_bounds_cover_everything():
+    from nerf import parallel
+    for n in (0, 1, 7, 400, 401):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -15,6 +15,7 @@
 //   * bf16 mode: v_mfma_f32_32x32x16_bf16, 8 waves x 32 points per workgroup, 2 waves / SIMD;
 //     fp32 mode: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), 4 waves x 32 points, 1 wave / SIMD.
 // MFMA-bound: 1,186,816 FLOP per point (D8/W256) against 16 B written per point.
+#include <cstdlib>
 #include <utility>
 
 #include "mlp_layout.h"
@@ -34,9 +35,11 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
-constexpr int kRingPhases = 4;
+constexpr int kRingPhases = 6;
 constexpr int kSlotBytes = kPhasePieces * kPieceBytes;  // 16 KiB
-constexpr int kRingBytes = kRingPhases * kSlotBytes;    // 64 KiB
+constexpr int kRingBytes = kRingPhases * kSlotBytes;    // 96 KiB
+constexpr int kPrefetch = 4;                            // A-fragment pieces read ahead of the MFMA that uses them
+constexpr int kInRows = 12;                             // per-wave input staging rows (64 floats each)
 
 template <bool BF16> struct Prec;
 template <> struct Prec<true> {
@@ -76,42 +79,119 @@ struct FwdParams {
 };
 
 // ---- weight pipeline: LDS ring fed by LDS-DMA -------------------------------------------------------
+// Ring of 6 x 16 KiB phases.  At the barrier that opens phase p every wave has waited for its own DMAs of
+// phases <= p+1, so after the barrier phases p AND p+1 are fully landed: the A-fragment read stream (a FIFO of
+// kPrefetch pieces per wave) runs continuously across phase boundaries.  Phases p+2..p+4 stay in flight
+// (counted vmcnt, never 0 in the loop); phase p+5 is issued into the slot phase p-1 just vacated.
+// Extra VMEM ops (input DMAs, the output store) are younger or older than the DMAs a wait must cover and,
+// because VMEM ops retire in order, can only make a counted wait stricter, never weaker.
 template <int WAVES>
 struct Pipe {
   static constexpr int PER_WAVE = kPhasePieces / WAVES;
   char* ring;           // LDS
-  const char* wsrc;     // global pieces, + lane*16 folded in
+  unsigned ring_addr;   // its 32-bit LDS byte address (for M0)
+  const char* wsrc;     // global pieces (wave-uniform pointer)
   unsigned total_bytes; // stream length in bytes
   unsigned q_issue;     // byte offset of the next phase to DMA (wave-uniform)
-  unsigned slot_wr, slot_rd;
+  unsigned slot_wr, slot_nxt;
   unsigned wave;
-  const char* rd;       // LDS read pointer of the current phase (+ lane*16)
+  unsigned pend_src, pend_dst;  // this wave's DMA of the phase being issued (wave-uniform byte offsets)
+  const char* rd_cur;   // LDS read pointers (+ lane*16) of the current and the next phase
+  const char* rd_nxt;
   unsigned lane16;
+  f32x4 af[kPrefetch];  // A-fragment FIFO: af[pos % kPrefetch] holds piece `pos` when it is consumed
 
-  __device__ __forceinline__ void issue_phase() {
-    char* dst = ring + slot_wr * kSlotBytes + wave * (PER_WAVE * kPieceBytes);
-    const char* src = wsrc + q_issue + wave * (PER_WAVE * kPieceBytes);
-#pragma unroll
-    for (int e = 0; e < PER_WAVE; ++e) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(src + e * kPieceBytes),
-          (__attribute__((address_space(3))) void*)(dst + e * kPieceBytes), 16, 0, 0);
+  // DMA of one phase = PER_WAVE consecutive pieces per wave, as ONE opaque asm statement: SGPR-base form of
+  // global_load_lds (32-bit lane offset), M0 saved/restored inside the statement, and a wave-uniform skip
+  // branch *inside* the asm so the compiler sees straight-line code (a C++ branch here splits every phase into
+  // basic blocks and costs dozens of spilled registers).  The instruction offset advances both the global and
+  // the LDS address.  hipcc does not count these in its own waitcnt bookkeeping - the counted waits are ours.
+  __device__ __forceinline__ void dma_phase(unsigned src_off, unsigned dst_off, unsigned go) {
+#ifndef DN_EXP_NODMA
+    // every "s" operand must be provably wave-uniform: readfirstlane them (they are uniform by construction)
+    const unsigned long long src_bits = reinterpret_cast<unsigned long long>(wsrc + src_off);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(src_bits));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(src_bits >> 32));
+    const char* src = reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
+    const unsigned lds = __builtin_amdgcn_readfirstlane(ring_addr + dst_off);
+    go = __builtin_amdgcn_readfirstlane(go);
+    unsigned keep;
+    if constexpr (PER_WAVE == 2) {
+      asm volatile(
+          "s_cmp_lg_u32 %[go], 0\n\t"
+          "s_cbranch_scc0 .Ldn_dma_skip%=\n\t"
+          "s_mov_b32 %[keep], m0\n\t"
+          "s_mov_b32 m0, %[lds]\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %[voff], %[sbase]\n\t"
+          "global_load_lds_dwordx4 %[voff], %[sbase] offset:1024\n\t"
+          "s_mov_b32 m0, %[keep]\n"
+          ".Ldn_dma_skip%=:"
+          : [keep] "=&s"(keep)
+          : [go] "s"(go), [lds] "s"(lds), [voff] "v"(lane16), [sbase] "s"(src)
+          : "memory", "scc");
+    } else {
+      asm volatile(
+          "s_cmp_lg_u32 %[go], 0\n\t"
+          "s_cbranch_scc0 .Ldn_dma_skip%=\n\t"
+          "s_mov_b32 %[keep], m0\n\t"
+          "s_mov_b32 m0, %[lds]\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %[voff], %[sbase]\n\t"
+          "global_load_lds_dwordx4 %[voff], %[sbase] offset:1024\n\t"
+          "global_load_lds_dwordx4 %[voff], %[sbase] offset:2048\n\t"
+          "global_load_lds_dwordx4 %[voff], %[sbase] offset:3072\n\t"
+          "s_mov_b32 m0, %[keep]\n"
+          ".Ldn_dma_skip%=:"
+          : [keep] "=&s"(keep)
+          : [go] "s"(go), [lds] "s"(lds), [voff] "v"(lane16), [sbase] "s"(src)
+          : "memory", "scc");
     }
+#endif
+  }
+
+  __device__ __forceinline__ void advance_issue() {
+    pend_src = q_issue + wave * (PER_WAVE * kPieceBytes);
+    pend_dst = slot_wr * kSlotBytes + wave * (PER_WAVE * kPieceBytes);
     q_issue += kSlotBytes;
     if (q_issue >= total_bytes) q_issue = 0;
-    slot_wr = (slot_wr + 1) & (kRingPhases - 1);
+    slot_wr = (slot_wr + 1 == kRingPhases) ? 0 : slot_wr + 1;
+  }
+
+  __device__ __forceinline__ void issue_phase() {  // prologue only
+    advance_issue();
+    dma_phase(pend_src, pend_dst, 1u);
   }
 
   // Called at every 16-piece boundary of the (compile-time laid out) consumption sequence.
+  // With two waves per SIMD (bf16 build) the DMA issue is split: waves 0-3 issue right after the barrier, waves
+  // 4-7 eight pieces later (mid_phase), so a wave's DMA-issue time (an LDS-DMA costs ~60-180 issue cycles) is
+  // covered by its SIMD partner's MFMAs instead of both stalling the matrix pipe together.
   __device__ __forceinline__ void phase_begin() {
-    // own DMAs of this phase have landed once at most the two younger phases remain outstanding;
-    // lgkmcnt(0): this wave's LDS reads of the previous phase are complete before its slot is recycled.
-    if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    // (kRingPhases-3) younger phases may stay outstanding; lgkmcnt(0): this wave's LDS reads of the previous
+    // phase are complete before its slot is recycled (and the FIFO entries for this phase have arrived).
+    if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue_phase();  // phase p+3 into the slot phase p-1 just vacated
-    rd = ring + slot_rd * kSlotBytes + lane16;
-    slot_rd = (slot_rd + 1) & (kRingPhases - 1);
+    advance_issue();
+    dma_phase(pend_src, pend_dst, (WAVES == 4 || wave < 4) ? 1u : 0u);
+    rd_cur = rd_nxt;
+    slot_nxt = (slot_nxt + 1 == kRingPhases) ? 0 : slot_nxt + 1;
+    rd_nxt = ring + slot_nxt * kSlotBytes + lane16;
+  }
+
+  __device__ __forceinline__ void mid_phase() {
+    if constexpr (WAVES == 8) dma_phase(pend_src, pend_dst, wave >= 4 ? 1u : 0u);
+  }
+
+  // after consuming piece POS (position within the 16-piece phase), read piece POS + kPrefetch into its FIFO slot
+  template <int POS>
+  __device__ __forceinline__ void prefetch() {
+    constexpr int q = (POS % kPhasePieces) + kPrefetch;
+    const char* base = (q < kPhasePieces) ? rd_cur : rd_nxt;
+#ifndef DN_EXP_NOREAD
+    af[POS % kPrefetch] = *reinterpret_cast<const f32x4*>(base + (q % kPhasePieces) * kPieceBytes);
+#endif
   }
 };
 
@@ -130,10 +210,13 @@ __device__ __forceinline__ f32x16 mma_piece(f32x16 acc, f32x4 a_raw, typename Pr
 }
 
 // One GEMM stage: NT_OUT output tiles, KH hidden pieces + KP positional-encoding pieces per tile.
-// POS0 = piece position (mod 16) at which the stage starts; phase boundaries are compile-time.
-template <bool BF16, int NT_OUT, int KH, int KP, int POS0, class PipeT, class BH, class BP>
-__device__ __forceinline__ void run_stage(PipeT& pipe, f32x16 (&acc)[NT_OUT], const BH& bh, const BP& bp,
-                                          const char* bias_lds /* this lane-half's 64 B of tile 0 */) {
+// Each tile's K-reduction completes on its own, so only ONE 32x32 accumulator tile is live at a time; `emit`
+// consumes it (ReLU + convert into the next stage's B pieces, or pick the output rows) while the next tile's
+// MFMAs are already being issued.  POS0 = piece position (mod 16) at which the stage starts; phase boundaries
+// (counted vmcnt + barrier + next DMA) are compile-time positions in the unrolled sequence.
+template <bool BF16, int NT_OUT, int KH, int KP, int POS0, class PipeT, class BH, class BP, class Emit>
+__device__ __forceinline__ void run_stage(PipeT& pipe, const BH& bh, BP&& bp /* k -> PE piece */,
+                                          const char* bias_lds /* this lane-half's 64 B of tile 0 */, Emit&& emit) {
   constexpr int KT = KH + KP;
   static_for<NT_OUT>([&](auto nt_c) {
     constexpr int nt = decltype(nt_c)::value;
@@ -148,31 +231,52 @@ __device__ __forceinline__ void run_stage(PipeT& pipe, f32x16 (&acc)[NT_OUT], co
       constexpr int k = decltype(k_c)::value;
       constexpr int pos = POS0 + nt * KT + k;
       if constexpr (pos % kPhasePieces == 0) pipe.phase_begin();
-      const f32x4 araw = *reinterpret_cast<const f32x4*>(pipe.rd + (pos % kPhasePieces) * kPieceBytes);
+      if constexpr (pos % kPhasePieces == kPhasePieces / 2) pipe.mid_phase();
+      const f32x4 araw = pipe.af[pos % kPrefetch];
       if constexpr (k < KH) a = mma_piece<BF16>(a, araw, bh[k]);
-      else a = mma_piece<BF16>(a, araw, bp[k - KH]);
+      else a = mma_piece<BF16>(a, araw, bp(k - KH));
+      pipe.template prefetch<pos>();
+      // pin the interleave: the MFMA(s) of this piece, then the one LDS read that refills its FIFO slot
+      __builtin_amdgcn_sched_group_barrier(0x008, BF16 ? 1 : 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     });
-    acc[nt] = a;
+    // region boundary BEFORE the epilogue: emit(nt)'s VALU work may overlap tile nt+1's MFMAs, but whole tiles
+    // are not interleaved (that would keep several accumulator tiles live and spill)
+    __builtin_amdgcn_sched_barrier(0);
+    emit(nt_c, a);
   });
 }
 
-// accumulator tiles -> next stage's B pieces (ReLU optional), in place of the register-resident chain
-template <bool BF16, int NT, bool RELU, class BH>
-__device__ __forceinline__ void acc_to_pieces(const f32x16 (&acc)[NT], BH& bh) {
+// accumulator tile -> the next stage's B pieces (in the register-resident chain), optional ReLU.
+// bf16: convert first, then ReLU on the packed pairs as a signed-int16 max with 0 (a negative bf16 has its
+// sign bit set, i.e. is a negative int16; -0.0 -> +0.0): 4 v_pk_max_i16 instead of 8 v_max_f32 per piece.
+template <bool BF16, bool RELU, int S>
+__device__ __forceinline__ typename Prec<BF16>::BPiece make_piece(const f32x16& acc) {
   using P = Prec<BF16>;
-  static_for<NT>([&](auto nt_c) {
-    constexpr int nt = decltype(nt_c)::value;
-    static_for<P::PPT>([&](auto s_c) {
-      constexpr int s = decltype(s_c)::value;
-      typename P::BPiece piece;
+  typename P::BPiece piece;
+  if constexpr (BF16) {
 #pragma unroll
-      for (int e = 0; e < P::EPP; ++e) {
-        float v = acc[nt][s * P::EPP + e];
-        if (RELU) v = fmaxf(v, 0.0f);
-        if constexpr (BF16) piece[e] = static_cast<__bf16>(v); else piece[e] = v;
-      }
-      bh[nt * P::PPT + s] = piece;
-    });
+    for (int e = 0; e < 8; ++e) piece[e] = static_cast<__bf16>(acc[S * 8 + e]);
+    if constexpr (RELU) {
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      s16x8 bits = __builtin_bit_cast(s16x8, piece);
+      const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+      bits = __builtin_elementwise_max(bits, zero);
+      piece = __builtin_bit_cast(typename P::BPiece, bits);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) piece[e] = RELU ? fmaxf(acc[S * 4 + e], 0.0f) : acc[S * 4 + e];
+  }
+  return piece;
+}
+
+template <bool BF16, bool RELU, int NT, class BO>
+__device__ __forceinline__ void emit_pieces(const f32x16& acc, BO& bo) {
+  using P = Prec<BF16>;
+  static_for<P::PPT>([&](auto s_c) {
+    constexpr int s = decltype(s_c)::value;
+    bo[NT * P::PPT + s] = make_piece<BF16, RELU, s>(acc);
   });
 }
 
@@ -253,6 +357,42 @@ __global__ __launch_bounds__(Prec<BF16>::WAVES * 64, BF16 ? 2 : 1) void mlp_forw
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5;
   const int j = lane & 31;
+  // per-wave input staging rows (64 floats each): 0-2 origin / point, 3-5 direction, 6 depth, 7-9 view direction
+  float* inbuf = reinterpret_cast<float*>(smem + kRingBytes + p.bias_bytes) + wave * (kInRows * 32);
+  // per-wave copy of the xyz-encoding B pieces (re-read at layer1 and at the skip layers instead of pinning
+  // 16-32 registers for the whole trunk)
+  char* pex = smem + kRingBytes + p.bias_bytes + WAVES * kInRows * 32 * 4 + wave * (KXP * kPieceBytes) + lane * 16;
+
+  // Stage the inputs of a tile by LDS-DMA (4 B per lane, per-lane source address): no VGPR-destination load is
+  // ever in flight next to the weight DMAs, so the compiler never drains the pipeline with vmcnt(0).
+  auto issue_inputs = [&](long long tile) {
+    long long pt = tile * PTS_PER_WG + wave * 32 + j;
+    if (pt >= p.n_points) pt = p.n_points - 1;
+    auto dma = [&](const float* src, int row) {
+      // lanes j and j+32 share a point: the low half stages it (an LDS-DMA lane writes base + lane*4)
+      if (lane < 32)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(inbuf + row * 32), 4, 0, 0);
+    };
+    if (p.mode == 0) {
+      const float* r = p.rays + (pt / p.S) * p.ray_stride;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dma(r + c, c);
+      dma(p.z + pt, 6);
+      if (p.use_viewdirs) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dma(r + 8 + c, 7 + c);
+      }
+    } else if (p.mode == 1) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dma(p.pts + pt * 3 + c, c);
+      if (p.use_viewdirs) {
+        const float* v = p.viewdirs + (pt / p.S) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dma(v + c, 7 + c);
+      }
+    }
+  };
 
   // biases -> LDS once per workgroup (fp32, pre-permuted [tile][half][16])
   {
@@ -260,22 +400,28 @@ __global__ __launch_bounds__(Prec<BF16>::WAVES * 64, BF16 ? 2 : 1) void mlp_forw
     f32x4* l = reinterpret_cast<f32x4*>(bias_lds);
     for (int i = threadIdx.x; i < p.bias_bytes / 16; i += WAVES * 64) l[i] = g[i];
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __syncthreads();
+  issue_inputs(blockIdx.x);
 
   Pipe<WAVES> pipe;
   pipe.ring = ring;
+  pipe.ring_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)ring));
   pipe.lane16 = lane * 16;
-  pipe.wsrc = p.packed + p.bias_bytes + lane * 16;
+  pipe.wsrc = p.packed + p.bias_bytes;
   pipe.total_bytes = static_cast<unsigned>(p.total_pieces) * kPieceBytes;
   pipe.q_issue = 0;
   pipe.slot_wr = 0;
-  pipe.slot_rd = 0;
   pipe.wave = wave;
-  pipe.rd = ring + lane * 16;
-  pipe.issue_phase();
-  pipe.issue_phase();
-  pipe.issue_phase();
+#pragma unroll
+  for (int ph = 0; ph < kRingPhases - 1; ++ph) pipe.issue_phase();
+  // one-time full drain: biases, first inputs and the first five phases are resident
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  pipe.slot_nxt = 0;
+  pipe.rd_cur = ring + lane * 16;
+  pipe.rd_nxt = ring + lane * 16;  // phase_begin() of phase 0 turns this into rd_cur
+#pragma unroll
+  for (int e = 0; e < kPrefetch; ++e)
+    pipe.af[e] = *reinterpret_cast<const f32x4*>(pipe.rd_nxt + e * kPieceBytes);
 
   const char* bias_half = bias_lds + h * 64;
 
@@ -284,68 +430,76 @@ __global__ __launch_bounds__(Prec<BF16>::WAVES * 64, BF16 ? 2 : 1) void mlp_forw
     long long pt = tile * PTS_PER_WG + wave * 32 + j;
     const bool live = pt < p.n_points;
     if (!live) pt = p.n_points - 1;
-    BPiece bx[KXP];
     float vd[3] = {0.f, 0.f, 0.f};
+    {
+    BPiece bx[KXP];
     if (p.mode == 2) {
       const float* row = p.enc + pt * p.enc_ld;
       gather_pieces<BF16, LX, KXP>(row, h, bx);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
+      // staged by this wave's own DMAs one tile ago; VMEM ops retire in order, so every counted wait since then
+      // (>= 70 phases, each leaving at most 6/12 younger ops outstanding) has covered them
+      float in[10];
+#pragma unroll
+      for (int c = 0; c < 10; ++c) in[c] = inbuf[c * 32 + j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const long long nxt = tile + gridDim.x;
+      if (nxt < p.n_tiles) issue_inputs(nxt);
       float x[3];
       if (p.mode == 0) {
-        const long long ray = pt / p.S;
-        const float* r = p.rays + ray * p.ray_stride;
-        const float zv = p.z[pt];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) x[c] = r[c] + r[3 + c] * zv;  // plain mul then add (train_utils.py:136)
-        if (p.use_viewdirs) { vd[0] = r[8]; vd[1] = r[9]; vd[2] = r[10]; }
+        for (int c = 0; c < 3; ++c) x[c] = in[c] + in[3 + c] * in[6];  // plain mul then add (train_utils.py:136)
       } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) x[c] = p.pts[pt * 3 + c];
-        if (p.use_viewdirs) {
-          const long long ray = pt / p.S;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) vd[c] = p.viewdirs[ray * 3 + c];
-        }
+        for (int c = 0; c < 3; ++c) x[c] = in[c];
       }
+      if (p.use_viewdirs) { vd[0] = in[7]; vd[1] = in[8]; vd[2] = in[9]; }
       encode_pieces<BF16, LX, KXP>(x, p.fx, h, bx);
     }
-    // inputs are ordinary VMEM loads: drain so the counted vmcnt below only ever sees weight DMAs
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    BPiece bh[KH];
-    f32x16 acc[NT];
-    int bias_tile = 0;
-    // ---- layer1: xyz encoding -> W, no activation (models.py:238) ----
-    {
-      BPiece none[1];
-      run_stage<BF16, NT, 0, KXP, 0>(pipe, acc, none, bx, bias_half);
-      acc_to_pieces<BF16, NT, false>(acc, bh);
-      bias_tile += NT;
+#pragma unroll
+    for (int k = 0; k < KXP; ++k) *reinterpret_cast<BPiece*>(pex + k * kPieceBytes) = bx[k];
     }
-    // ---- layers_xyz[i]: (cat(x, xyz) on skip layers) -> W, ReLU (models.py:239-246) ----
-    for (int i = 0; i < p.D - 1; ++i) {
-      if ((p.skip_mask >> i) & 1u) {
-        run_stage<BF16, NT, KH, KXP, 0>(pipe, acc, bh, bx, bias_half + bias_tile * 128);
-      } else {
-        BPiece none[1];
-        run_stage<BF16, NT, KH, 0, 0>(pipe, acc, bh, none, bias_half + bias_tile * 128);
-      }
-      acc_to_pieces<BF16, NT, true>(acc, bh);
+    auto pe_xyz = [&](int k) { return *reinterpret_cast<const BPiece*>(pex + k * kPieceBytes); };
+    auto no_pe = [&](int) { return BPiece{}; };
+
+    BPiece ba[KH], bb[KH];
+    BPiece none[1];
+    int bias_tile = 0;
+    // One trunk layer: layers_xyz[i] on (cat(x, xyz) when it is a skip layer) -> W, ReLU (models.py:239-246)
+    auto trunk_layer = [&](int i, const BPiece (&bin)[KH], BPiece (&bout)[KH]) {
+      auto emit = [&](auto nt_c, const f32x16& acc) { emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bout); };
+      if ((p.skip_mask >> i) & 1u) run_stage<BF16, NT, KH, KXP, 0>(pipe, bin, pe_xyz, bias_half + bias_tile * 128, emit);
+      else run_stage<BF16, NT, KH, 0, 0>(pipe, bin, no_pe, bias_half + bias_tile * 128, emit);
       bias_tile += NT;
+    };
+    // ---- layer1: xyz encoding -> W, no activation (models.py:238) ----
+    run_stage<BF16, NT, 0, KXP, 0>(pipe, none, pe_xyz, bias_half, [&](auto nt_c, const f32x16& acc) {
+      emit_pieces<BF16, false, decltype(nt_c)::value>(acc, ba);
+    });
+    bias_tile += NT;
+    // ---- trunk, two layers per iteration so the activations ping-pong between two register sets ----
+    int i = 0;
+    for (; i + 1 < p.D - 1; i += 2) {
+      trunk_layer(i, ba, bb);
+      trunk_layer(i + 1, bb, ba);
+    }
+    if (i < p.D - 1) {
+      trunk_layer(i, ba, bb);
+#pragma unroll
+      for (int k = 0; k < KH; ++k) ba[k] = bb[k];
     }
     float out4[4];
     if (p.use_viewdirs) {
       // ---- fc_alpha (extra tile, streamed first) + fc_feat with ReLU (models.py:248-249) ----
-      BPiece none[1];
       constexpr int POS_A = 0;
-      {
-        f32x16 at[1];
-        run_stage<BF16, 1, KH, 0, POS_A>(pipe, at, bh, none, bias_half + bias_tile * 128);
-        out4[3] = at[0][0];  // row 0 of the tile: lanes 0..31, register 0
-      }
+      run_stage<BF16, 1, KH, 0, POS_A>(pipe, ba, no_pe, bias_half + bias_tile * 128,
+                                        [&](auto, const f32x16& acc) { out4[3] = acc[0]; });  // row 0: lanes 0..31, reg 0
       constexpr int POS_F = (POS_A + KH) % kPhasePieces;
-      run_stage<BF16, NT, KH, 0, POS_F>(pipe, acc, bh, none, bias_half + (bias_tile + 1) * 128);
-      acc_to_pieces<BF16, NT, true>(acc, bh);
+      run_stage<BF16, NT, KH, 0, POS_F>(pipe, ba, no_pe, bias_half + (bias_tile + 1) * 128,
+                                         [&](auto nt_c, const f32x16& acc) {
+                                           emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bb);
+                                         });
       bias_tile += NT + 1;
       // ---- layers_dir[0] on cat(feat, view) -> W/2, ReLU (models.py:250-252) ----
       BPiece bd[KDP];
@@ -353,33 +507,30 @@ __global__ __launch_bounds__(Prec<BF16>::WAVES * 64, BF16 ? 2 : 1) void mlp_forw
       else encode_pieces<BF16, LD, KDP>(vd, p.fd, h, bd);
       if (p.mode == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       constexpr int POS_D = (POS_F + NT * KH) % kPhasePieces;
-      f32x16 accd[NT / 2];
-      run_stage<BF16, NT / 2, KH, KDP, POS_D>(pipe, accd, bh, bd, bias_half + bias_tile * 128);
       BPiece bg[KH / 2];
-      acc_to_pieces<BF16, NT / 2, true>(accd, bg);
+      auto pe_dir = [&](int k) { return bd[k]; };
+      run_stage<BF16, NT / 2, KH, KDP, POS_D>(pipe, bb, pe_dir, bias_half + bias_tile * 128,
+                                               [&](auto nt_c, const f32x16& acc) {
+                                                 emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bg);
+                                               });
       bias_tile += NT / 2;
       // ---- fc_rgb (models.py:253) ----
       constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % kPhasePieces;
-      f32x16 ar[1];
-      run_stage<BF16, 1, KH / 2, 0, POS_R>(pipe, ar, bg, none, bias_half + bias_tile * 128);
-      out4[0] = ar[0][0]; out4[1] = ar[0][1]; out4[2] = ar[0][2];
-      // the stream is padded to a whole number of phases; nothing to skip: every tail variant ends aligned
+      run_stage<BF16, 1, KH / 2, 0, POS_R>(pipe, bg, no_pe, bias_half + bias_tile * 128, [&](auto, const f32x16& acc) {
+        out4[0] = acc[0]; out4[1] = acc[1]; out4[2] = acc[2];
+      });
       static_assert((POS_R + KH / 2) % kPhasePieces == 0, "tail must end on a phase boundary");
     } else {
-      BPiece none[1];
-      f32x16 ao[1];
-      run_stage<BF16, 1, KH, 0, 0>(pipe, ao, bh, none, bias_half + bias_tile * 128);
-      out4[0] = ao[0][0]; out4[1] = ao[0][1]; out4[2] = ao[0][2]; out4[3] = ao[0][3];
-      if constexpr (KH % kPhasePieces != 0) {
-        // consume the padding phase remainder: nothing to read, positions are per-phase relative
-      }
+      // ---- fc_out (models.py:256); the stream is padded to a whole phase after it ----
+      run_stage<BF16, 1, KH, 0, 0>(pipe, ba, no_pe, bias_half + bias_tile * 128, [&](auto, const f32x16& acc) {
+        out4[0] = acc[0]; out4[1] = acc[1]; out4[2] = acc[2]; out4[3] = acc[3];
+      });
     }
     if (live && h == 0) {
       f32x4 o;
       o[0] = out4[0]; o[1] = out4[1]; o[2] = out4[2]; o[3] = out4[3];
       *reinterpret_cast<f32x4*>(p.out + pt * 4) = o;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
@@ -463,7 +614,7 @@ __global__ void pack_kernel(NetLayout L, PackPtrs ptrs, char* __restrict__ packe
 template <int W, int LX, int LD, bool BF16>
 static int launch_forward(const FwdParams& p, hipStream_t stream) {
   auto kern = mlp_forward_kernel<W, LX, LD, BF16>;
-  const size_t lds = kRingBytes + p.bias_bytes;
+  const size_t lds = kRingBytes + p.bias_bytes + Prec<BF16>::WAVES * (kInRows * 32 * sizeof(float) + (round_up(3 + 6 * LX, 16) / (2 * Prec<BF16>::EPP)) * kPieceBytes);
   static thread_local bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

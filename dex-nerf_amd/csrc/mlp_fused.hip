@@ -35,25 +35,28 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
-constexpr int kRingPhases = 6;
+constexpr int kRingPhases = 5;
 constexpr int kSlotBytes = kPhasePieces * kPieceBytes;  // 16 KiB
-constexpr int kRingBytes = kRingPhases * kSlotBytes;    // 96 KiB
+constexpr int kRingBytes = kRingPhases * kSlotBytes;    // 80 KiB
 constexpr int kPrefetch = 4;                            // A-fragment pieces read ahead of the MFMA that uses them
-constexpr int kInRows = 12;                             // per-wave input staging rows (64 floats each)
+constexpr int kInRows = 10;                             // per-wave input staging rows
 
 template <bool BF16> struct Prec;
 template <> struct Prec<true> {
   using BPiece = bf16x8;
   static constexpr int EPP = 8;    // k-values (elements) per lane per piece
   static constexpr int PPT = 2;    // pieces per 32-row hidden tile
-  static constexpr int WAVES = 8;
 };
 template <> struct Prec<false> {
   using BPiece = f32x4;
   static constexpr int EPP = 4;
   static constexpr int PPT = 4;
-  static constexpr int WAVES = 4;
 };
+// Geometry: PT point-tiles (of 32 points) per wave.  bf16 default: PT=1 -> 8 waves x 32 points, two waves per
+// SIMD.  bf16 PT=2 -> 4 waves x 64 points, one wave per SIMD (every A fragment read from LDS feeds two MFMAs;
+// halves the LDS read traffic but a lone wave per SIMD hides no stall - measured 4 % slower).  fp32: PT=1,
+// 4 waves x 32 points, one wave per SIMD.
+template <bool BF16, int PT> constexpr int waves_of() { return (BF16 && PT == 1) ? 8 : 4; }
 
 struct FwdParams {
   const char* packed;   // [bias region][pieces]
@@ -79,10 +82,10 @@ struct FwdParams {
 };
 
 // ---- weight pipeline: LDS ring fed by LDS-DMA -------------------------------------------------------
-// Ring of 6 x 16 KiB phases.  At the barrier that opens phase p every wave has waited for its own DMAs of
+// Ring of 5 x 16 KiB phases.  At the barrier that opens phase p every wave has waited for its own DMAs of
 // phases <= p+1, so after the barrier phases p AND p+1 are fully landed: the A-fragment read stream (a FIFO of
-// kPrefetch pieces per wave) runs continuously across phase boundaries.  Phases p+2..p+4 stay in flight
-// (counted vmcnt, never 0 in the loop); phase p+5 is issued into the slot phase p-1 just vacated.
+// kPrefetch pieces per wave) runs continuously across phase boundaries.  Phases p+2, p+3 stay in flight
+// (counted vmcnt, never 0 in the loop); phase p+4 is issued into the slot phase p-1 just vacated.
 // Extra VMEM ops (input DMAs, the output store) are younger or older than the DMAs a wait must cover and,
 // because VMEM ops retire in order, can only make a counted wait stricter, never weaker.
 template <int WAVES>
@@ -170,8 +173,14 @@ struct Pipe {
   __device__ __forceinline__ void phase_begin() {
     // (kRingPhases-3) younger phases may stay outstanding; lgkmcnt(0): this wave's LDS reads of the previous
     // phase are complete before its slot is recycled (and the FIFO entries for this phase have arrived).
-    if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    static_assert(kRingPhases == 5, "the counted waits below assume two younger phases in flight");
+#ifdef DN_EXP_SHALLOW  // ablation: only one younger phase in flight
+    if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+#else
+    if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
     advance_issue();
     dma_phase(pend_src, pend_dst, (WAVES == 4 || wave < 4) ? 1u : 0u);
@@ -209,41 +218,48 @@ __device__ __forceinline__ f32x16 mma_piece(f32x16 acc, f32x4 a_raw, typename Pr
   }
 }
 
-// One GEMM stage: NT_OUT output tiles, KH hidden pieces + KP positional-encoding pieces per tile.
-// Each tile's K-reduction completes on its own, so only ONE 32x32 accumulator tile is live at a time; `emit`
-// consumes it (ReLU + convert into the next stage's B pieces, or pick the output rows) while the next tile's
+// One GEMM stage: NT_OUT output tiles, KH hidden pieces + KP positional-encoding pieces per tile, for the PT
+// point-tiles this wave owns (each A fragment is read once and feeds PT MFMAs).
+// Each tile's K-reduction completes on its own, so only PT 32x32 accumulator tiles are live at a time; `emit`
+// consumes them (ReLU + convert into the next stage's B pieces, or pick the output rows) while the next tile's
 // MFMAs are already being issued.  POS0 = piece position (mod 16) at which the stage starts; phase boundaries
 // (counted vmcnt + barrier + next DMA) are compile-time positions in the unrolled sequence.
-template <bool BF16, int NT_OUT, int KH, int KP, int POS0, class PipeT, class BH, class BP, class Emit>
-__device__ __forceinline__ void run_stage(PipeT& pipe, const BH& bh, BP&& bp /* k -> PE piece */,
+template <bool BF16, int PT, int NT_OUT, int KH, int KP, int POS0, class PipeT, class BH, class BP, class Emit>
+__device__ __forceinline__ void run_stage(PipeT& pipe, const BH& bh /* [PT][KH] */, BP&& bp /* (t, k) -> PE piece */,
                                           const char* bias_lds /* this lane-half's 64 B of tile 0 */, Emit&& emit) {
   constexpr int KT = KH + KP;
   static_for<NT_OUT>([&](auto nt_c) {
     constexpr int nt = decltype(nt_c)::value;
     const f32x4* bptr = reinterpret_cast<const f32x4*>(bias_lds + nt * 128);
     const f32x4 b0 = bptr[0], b1 = bptr[1], b2 = bptr[2], b3 = bptr[3];
-    f32x16 a;
-    a[0] = b0[0]; a[1] = b0[1]; a[2] = b0[2]; a[3] = b0[3];
-    a[4] = b1[0]; a[5] = b1[1]; a[6] = b1[2]; a[7] = b1[3];
-    a[8] = b2[0]; a[9] = b2[1]; a[10] = b2[2]; a[11] = b2[3];
-    a[12] = b3[0]; a[13] = b3[1]; a[14] = b3[2]; a[15] = b3[3];
+    f32x16 a[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      a[t][0] = b0[0]; a[t][1] = b0[1]; a[t][2] = b0[2]; a[t][3] = b0[3];
+      a[t][4] = b1[0]; a[t][5] = b1[1]; a[t][6] = b1[2]; a[t][7] = b1[3];
+      a[t][8] = b2[0]; a[t][9] = b2[1]; a[t][10] = b2[2]; a[t][11] = b2[3];
+      a[t][12] = b3[0]; a[t][13] = b3[1]; a[t][14] = b3[2]; a[t][15] = b3[3];
+    }
     static_for<KT>([&](auto k_c) {
       constexpr int k = decltype(k_c)::value;
       constexpr int pos = POS0 + nt * KT + k;
       if constexpr (pos % kPhasePieces == 0) pipe.phase_begin();
       if constexpr (pos % kPhasePieces == kPhasePieces / 2) pipe.mid_phase();
       const f32x4 araw = pipe.af[pos % kPrefetch];
-      if constexpr (k < KH) a = mma_piece<BF16>(a, araw, bh[k]);
-      else a = mma_piece<BF16>(a, araw, bp(k - KH));
+      static_for<PT>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        if constexpr (k < KH) a[t] = mma_piece<BF16>(a[t], araw, bh[t][k]);
+        else a[t] = mma_piece<BF16>(a[t], araw, bp(t, k - KH));
+      });
       pipe.template prefetch<pos>();
-      // pin the interleave: the MFMA(s) of this piece, then the one LDS read that refills its FIFO slot
-      __builtin_amdgcn_sched_group_barrier(0x008, BF16 ? 1 : 4, 0);
+      // pin the interleave: the MFMAs of this piece, then the one LDS read that refills its FIFO slot
+      __builtin_amdgcn_sched_group_barrier(0x008, (BF16 ? 1 : 4) * PT, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     });
     // region boundary BEFORE the epilogue: emit(nt)'s VALU work may overlap tile nt+1's MFMAs, but whole tiles
     // are not interleaved (that would keep several accumulator tiles live and spill)
     __builtin_amdgcn_sched_barrier(0);
-    emit(nt_c, a);
+    static_for<PT>([&](auto t_c) { emit(nt_c, t_c, a[decltype(t_c)::value]); });
   });
 }
 
@@ -338,16 +354,17 @@ __device__ __forceinline__ void gather_pieces(const float* row, int h, BP& bp) {
   });
 }
 
-template <int W, int LX, int LD, bool BF16>
-__global__ __launch_bounds__(Prec<BF16>::WAVES * 64, BF16 ? 2 : 1) void mlp_forward_kernel(FwdParams p) {
+template <int W, int LX, int LD, bool BF16, int PT>
+__global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2 : 1)) void mlp_forward_kernel(FwdParams p) {
   using P = Prec<BF16>;
   using BPiece = typename P::BPiece;
   constexpr int NT = W / 32;
   constexpr int KH = NT * P::PPT;                      // hidden pieces of a W-wide input
   constexpr int KXP = round_up(3 + 6 * LX, 16) / (2 * P::EPP);  // PE xyz pieces
   constexpr int KDP = round_up(3 + 6 * LD, 16) / (2 * P::EPP);  // PE dir pieces
-  constexpr int WAVES = P::WAVES;
-  constexpr int PTS_PER_WG = 32 * WAVES;
+  constexpr int WAVES = waves_of<BF16, PT>();
+  constexpr int PTS_PER_WAVE = 32 * PT;
+  constexpr int PTS_PER_WG = PTS_PER_WAVE * WAVES;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;
@@ -357,22 +374,24 @@ __global__ __launch_bounds__(Prec<BF16>::WAVES * 64, BF16 ? 2 : 1) void mlp_forw
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5;
   const int j = lane & 31;
-  // per-wave input staging rows (64 floats each): 0-2 origin / point, 3-5 direction, 6 depth, 7-9 view direction
-  float* inbuf = reinterpret_cast<float*>(smem + kRingBytes + p.bias_bytes) + wave * (kInRows * 32);
+  // per-wave input staging rows (PTS_PER_WAVE floats each): 0-2 origin / point, 3-5 direction, 6 depth, 7-9 view dir
+  float* inbuf = reinterpret_cast<float*>(smem + kRingBytes + p.bias_bytes) + wave * (kInRows * PTS_PER_WAVE);
   // per-wave copy of the xyz-encoding B pieces (re-read at layer1 and at the skip layers instead of pinning
-  // 16-32 registers for the whole trunk)
-  char* pex = smem + kRingBytes + p.bias_bytes + WAVES * kInRows * 32 * 4 + wave * (KXP * kPieceBytes) + lane * 16;
+  // registers for the whole trunk)
+  char* pex = smem + kRingBytes + p.bias_bytes + WAVES * kInRows * PTS_PER_WAVE * 4 +
+              wave * (PT * (KXP + KDP) * kPieceBytes) + lane * 16;
+  char* ped = pex + PT * KXP * kPieceBytes;  // the view-direction encoding pieces, used once near the end of the tile
 
   // Stage the inputs of a tile by LDS-DMA (4 B per lane, per-lane source address): no VGPR-destination load is
   // ever in flight next to the weight DMAs, so the compiler never drains the pipeline with vmcnt(0).
+  // Lane l (< PTS_PER_WAVE) stages point l of this wave's PTS_PER_WAVE points.
   auto issue_inputs = [&](long long tile) {
-    long long pt = tile * PTS_PER_WG + wave * 32 + j;
+    long long pt = tile * PTS_PER_WG + wave * PTS_PER_WAVE + lane;
     if (pt >= p.n_points) pt = p.n_points - 1;
     auto dma = [&](const float* src, int row) {
-      // lanes j and j+32 share a point: the low half stages it (an LDS-DMA lane writes base + lane*4)
-      if (lane < 32)
+      if (lane < PTS_PER_WAVE)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(inbuf + row * 32), 4, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(inbuf + row * PTS_PER_WAVE), 4, 0, 0);
     };
     if (p.mode == 0) {
       const float* r = p.rays + (pt / p.S) * p.ray_stride;
@@ -426,56 +445,78 @@ __global__ __launch_bounds__(Prec<BF16>::WAVES * 64, BF16 ? 2 : 1) void mlp_forw
   const char* bias_half = bias_lds + h * 64;
 
   for (long long tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-    // ---- inputs of this lane's point (lanes j and j+32 share a point) ----
-    long long pt = tile * PTS_PER_WG + wave * 32 + j;
-    const bool live = pt < p.n_points;
-    if (!live) pt = p.n_points - 1;
-    float vd[3] = {0.f, 0.f, 0.f};
-    {
-    BPiece bx[KXP];
-    if (p.mode == 2) {
-      const float* row = p.enc + pt * p.enc_ld;
-      gather_pieces<BF16, LX, KXP>(row, h, bx);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
+    // ---- inputs: lanes j and j+32 share the points {t*32 + j} of this wave ----
+    // Everything a lane derives from its inputs (both encodings) goes to LDS here, so no VGPR is carried across
+    // the trunk: spilled carries would be reloaded with vmcnt(0) waits that drain the weight pipeline.
+    if (p.mode != 2) {
       // staged by this wave's own DMAs one tile ago; VMEM ops retire in order, so every counted wait since then
       // (>= 70 phases, each leaving at most 6/12 younger ops outstanding) has covered them
-      float in[10];
+      float in[PT][10];
 #pragma unroll
-      for (int c = 0; c < 10; ++c) in[c] = inbuf[c * 32 + j];
+      for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int c = 0; c < 10; ++c) in[t][c] = inbuf[c * PTS_PER_WAVE + t * 32 + j];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const long long nxt = tile + gridDim.x;
       if (nxt < p.n_tiles) issue_inputs(nxt);
-      float x[3];
-      if (p.mode == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) x[c] = in[c] + in[3 + c] * in[6];  // plain mul then add (train_utils.py:136)
-      } else {
+      for (int t = 0; t < PT; ++t) {
+        float x[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) x[c] = in[c];
+        for (int c = 0; c < 3; ++c)  // plain mul then add (train_utils.py:136)
+          x[c] = (p.mode == 0) ? in[t][c] + in[t][3 + c] * in[t][6] : in[t][c];
+        BPiece bx[KXP];
+        encode_pieces<BF16, LX, KXP>(x, p.fx, h, bx);
+#pragma unroll
+        for (int k = 0; k < KXP; ++k) *reinterpret_cast<BPiece*>(pex + (t * KXP + k) * kPieceBytes) = bx[k];
+        if (p.use_viewdirs) {
+          float vdir[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) vdir[c] = in[t][7 + c];
+          BPiece bd[KDP];
+          encode_pieces<BF16, LD, KDP>(vdir, p.fd, h, bd);
+#pragma unroll
+          for (int k = 0; k < KDP; ++k) *reinterpret_cast<BPiece*>(ped + (t * KDP + k) * kPieceBytes) = bd[k];
+        }
       }
-      if (p.use_viewdirs) { vd[0] = in[7]; vd[1] = in[8]; vd[2] = in[9]; }
-      encode_pieces<BF16, LX, KXP>(x, p.fx, h, bx);
-    }
+    } else {
 #pragma unroll
-    for (int k = 0; k < KXP; ++k) *reinterpret_cast<BPiece*>(pex + k * kPieceBytes) = bx[k];
+      for (int t = 0; t < PT; ++t) {
+        long long pt = tile * PTS_PER_WG + wave * PTS_PER_WAVE + j + t * 32;
+        if (pt >= p.n_points) pt = p.n_points - 1;
+        BPiece bx[KXP];
+        gather_pieces<BF16, LX, KXP>(p.enc + pt * p.enc_ld, h, bx);
+        BPiece bd[KDP];
+        if (p.use_viewdirs) gather_pieces<BF16, LD, KDP>(p.enc + pt * p.enc_ld + (3 + 6 * LX), h, bd);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < KXP; ++k) *reinterpret_cast<BPiece*>(pex + (t * KXP + k) * kPieceBytes) = bx[k];
+        if (p.use_viewdirs) {
+#pragma unroll
+          for (int k = 0; k < KDP; ++k) *reinterpret_cast<BPiece*>(ped + (t * KDP + k) * kPieceBytes) = bd[k];
+        }
+      }
     }
-    auto pe_xyz = [&](int k) { return *reinterpret_cast<const BPiece*>(pex + k * kPieceBytes); };
-    auto no_pe = [&](int) { return BPiece{}; };
+    auto pe_xyz = [&](int t, int k) { return *reinterpret_cast<const BPiece*>(pex + (t * KXP + k) * kPieceBytes); };
+    auto no_pe = [&](int, int) { return BPiece{}; };
 
-    BPiece ba[KH], bb[KH];
-    BPiece none[1];
+    BPiece ba[PT][KH], bb[PT][KH];
+    BPiece none[PT][1];
     int bias_tile = 0;
     // One trunk layer: layers_xyz[i] on (cat(x, xyz) when it is a skip layer) -> W, ReLU (models.py:239-246)
-    auto trunk_layer = [&](int i, const BPiece (&bin)[KH], BPiece (&bout)[KH]) {
-      auto emit = [&](auto nt_c, const f32x16& acc) { emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bout); };
-      if ((p.skip_mask >> i) & 1u) run_stage<BF16, NT, KH, KXP, 0>(pipe, bin, pe_xyz, bias_half + bias_tile * 128, emit);
-      else run_stage<BF16, NT, KH, 0, 0>(pipe, bin, no_pe, bias_half + bias_tile * 128, emit);
+    auto trunk_layer = [&](int i, const BPiece (&bin)[PT][KH], BPiece (&bout)[PT][KH]) {
+      auto emit = [&](auto nt_c, auto t_c, const f32x16& acc) {
+        emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bout[decltype(t_c)::value]);
+      };
+      if ((p.skip_mask >> i) & 1u)
+        run_stage<BF16, PT, NT, KH, KXP, 0>(pipe, bin, pe_xyz, bias_half + bias_tile * 128, emit);
+      else
+        run_stage<BF16, PT, NT, KH, 0, 0>(pipe, bin, no_pe, bias_half + bias_tile * 128, emit);
       bias_tile += NT;
     };
     // ---- layer1: xyz encoding -> W, no activation (models.py:238) ----
-    run_stage<BF16, NT, 0, KXP, 0>(pipe, none, pe_xyz, bias_half, [&](auto nt_c, const f32x16& acc) {
-      emit_pieces<BF16, false, decltype(nt_c)::value>(acc, ba);
+    run_stage<BF16, PT, NT, 0, KXP, 0>(pipe, none, pe_xyz, bias_half, [&](auto nt_c, auto t_c, const f32x16& acc) {
+      emit_pieces<BF16, false, decltype(nt_c)::value>(acc, ba[decltype(t_c)::value]);
     });
     bias_tile += NT;
     // ---- trunk, two layers per iteration so the activations ping-pong between two register sets ----
@@ -487,49 +528,57 @@ __global__ __launch_bounds__(Prec<BF16>::WAVES * 64, BF16 ? 2 : 1) void mlp_forw
     if (i < p.D - 1) {
       trunk_layer(i, ba, bb);
 #pragma unroll
-      for (int k = 0; k < KH; ++k) ba[k] = bb[k];
+      for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int k = 0; k < KH; ++k) ba[t][k] = bb[t][k];
     }
-    float out4[4];
+    float out4[PT][4];
     if (p.use_viewdirs) {
       // ---- fc_alpha (extra tile, streamed first) + fc_feat with ReLU (models.py:248-249) ----
       constexpr int POS_A = 0;
-      run_stage<BF16, 1, KH, 0, POS_A>(pipe, ba, no_pe, bias_half + bias_tile * 128,
-                                        [&](auto, const f32x16& acc) { out4[3] = acc[0]; });  // row 0: lanes 0..31, reg 0
+      run_stage<BF16, PT, 1, KH, 0, POS_A>(pipe, ba, no_pe, bias_half + bias_tile * 128,
+                                            [&](auto, auto t_c, const f32x16& acc) {
+                                              out4[decltype(t_c)::value][3] = acc[0];  // row 0: lanes 0..31, reg 0
+                                            });
       constexpr int POS_F = (POS_A + KH) % kPhasePieces;
-      run_stage<BF16, NT, KH, 0, POS_F>(pipe, ba, no_pe, bias_half + (bias_tile + 1) * 128,
-                                         [&](auto nt_c, const f32x16& acc) {
-                                           emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bb);
-                                         });
+      run_stage<BF16, PT, NT, KH, 0, POS_F>(pipe, ba, no_pe, bias_half + (bias_tile + 1) * 128,
+                                             [&](auto nt_c, auto t_c, const f32x16& acc) {
+                                               emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bb[decltype(t_c)::value]);
+                                             });
       bias_tile += NT + 1;
       // ---- layers_dir[0] on cat(feat, view) -> W/2, ReLU (models.py:250-252) ----
-      BPiece bd[KDP];
-      if (p.mode == 2) gather_pieces<BF16, LD, KDP>(p.enc + pt * p.enc_ld + (3 + 6 * LX), h, bd);
-      else encode_pieces<BF16, LD, KDP>(vd, p.fd, h, bd);
-      if (p.mode == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       constexpr int POS_D = (POS_F + NT * KH) % kPhasePieces;
-      BPiece bg[KH / 2];
-      auto pe_dir = [&](int k) { return bd[k]; };
-      run_stage<BF16, NT / 2, KH, KDP, POS_D>(pipe, bb, pe_dir, bias_half + bias_tile * 128,
-                                               [&](auto nt_c, const f32x16& acc) {
-                                                 emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bg);
-                                               });
+      BPiece bg[PT][KH / 2];
+      auto pe_dir = [&](int t, int k) { return *reinterpret_cast<const BPiece*>(ped + (t * KDP + k) * kPieceBytes); };
+      run_stage<BF16, PT, NT / 2, KH, KDP, POS_D>(pipe, bb, pe_dir, bias_half + bias_tile * 128,
+                                                   [&](auto nt_c, auto t_c, const f32x16& acc) {
+                                                     emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bg[decltype(t_c)::value]);
+                                                   });
       bias_tile += NT / 2;
       // ---- fc_rgb (models.py:253) ----
       constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % kPhasePieces;
-      run_stage<BF16, 1, KH / 2, 0, POS_R>(pipe, bg, no_pe, bias_half + bias_tile * 128, [&](auto, const f32x16& acc) {
-        out4[0] = acc[0]; out4[1] = acc[1]; out4[2] = acc[2];
-      });
+      run_stage<BF16, PT, 1, KH / 2, 0, POS_R>(pipe, bg, no_pe, bias_half + bias_tile * 128,
+                                                [&](auto, auto t_c, const f32x16& acc) {
+                                                  constexpr int t = decltype(t_c)::value;
+                                                  out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2];
+                                                });
       static_assert((POS_R + KH / 2) % kPhasePieces == 0, "tail must end on a phase boundary");
     } else {
       // ---- fc_out (models.py:256); the stream is padded to a whole phase after it ----
-      run_stage<BF16, 1, KH, 0, 0>(pipe, ba, no_pe, bias_half + bias_tile * 128, [&](auto, const f32x16& acc) {
-        out4[0] = acc[0]; out4[1] = acc[1]; out4[2] = acc[2]; out4[3] = acc[3];
-      });
+      run_stage<BF16, PT, 1, KH, 0, 0>(pipe, ba, no_pe, bias_half + bias_tile * 128,
+                                        [&](auto, auto t_c, const f32x16& acc) {
+                                          constexpr int t = decltype(t_c)::value;
+                                          out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2]; out4[t][3] = acc[3];
+                                        });
     }
-    if (live && h == 0) {
-      f32x4 o;
-      o[0] = out4[0]; o[1] = out4[1]; o[2] = out4[2]; o[3] = out4[3];
-      *reinterpret_cast<f32x4*>(p.out + pt * 4) = o;
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const long long pt = tile * PTS_PER_WG + wave * PTS_PER_WAVE + j + t * 32;
+      if (pt < p.n_points && h == 0) {
+        f32x4 o;
+        o[0] = out4[t][0]; o[1] = out4[t][1]; o[2] = out4[t][2]; o[3] = out4[t][3];
+        *reinterpret_cast<f32x4*>(p.out + pt * 4) = o;
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -611,10 +660,15 @@ __global__ void pack_kernel(NetLayout L, PackPtrs ptrs, char* __restrict__ packe
   }
 }
 
-template <int W, int LX, int LD, bool BF16>
-static int launch_forward(const FwdParams& p, hipStream_t stream) {
-  auto kern = mlp_forward_kernel<W, LX, LD, BF16>;
-  const size_t lds = kRingBytes + p.bias_bytes + Prec<BF16>::WAVES * (kInRows * 32 * sizeof(float) + (round_up(3 + 6 * LX, 16) / (2 * Prec<BF16>::EPP)) * kPieceBytes);
+template <int W, int LX, int LD, bool BF16, int PT>
+static int launch_forward(FwdParams p, hipStream_t stream) {
+  auto kern = mlp_forward_kernel<W, LX, LD, BF16, PT>;
+  constexpr int WAVES = waves_of<BF16, PT>();
+  constexpr int PTS_PER_WG = WAVES * 32 * PT;
+  constexpr int KXP = round_up(3 + 6 * LX, 16) / (2 * Prec<BF16>::EPP);
+  p.n_tiles = (p.n_points + PTS_PER_WG - 1) / PTS_PER_WG;
+  constexpr int KDP = round_up(3 + 6 * LD, 16) / (2 * Prec<BF16>::EPP);
+  const size_t lds = kRingBytes + p.bias_bytes + WAVES * (kInRows * 32 * PT * sizeof(float) + PT * (KXP + KDP) * kPieceBytes);
   static thread_local bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -625,16 +679,21 @@ static int launch_forward(const FwdParams& p, hipStream_t stream) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
   const long long grid = p.n_tiles < cus ? p.n_tiles : cus;
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(Prec<BF16>::WAVES * 64), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(WAVES * 64), lds, stream, p);
   return check_launch("mlp_forward");
 }
 
 static int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStream_t stream) {
   const bool bf = precision == DN_PREC_BF16;
-  p.n_tiles = (p.n_points + (bf ? 256 : 128) - 1) / (bf ? 256 : 128);
+  // bf16 geometry: PT=1 (8 waves x 32 points, two waves per SIMD) measured fastest (1327 vs 1277 TFLOP/s for
+  // PT=2 = 4 waves x 64 points, one wave per SIMD); DEXNERF_BF16_PT=2 selects the latter for experiments
+  static const int bf16_pt = [] { const char* e = getenv("DEXNERF_BF16_PT"); return (e && atoi(e) == 2) ? 2 : 1; }();
 #define DN_CASE(W_, LX_)                                                                     \
-  if (d.hidden_size == W_ && d.num_encoding_fn_xyz == LX_)                                   \
-    return bf ? launch_forward<W_, LX_, 4, true>(p, stream) : launch_forward<W_, LX_, 4, false>(p, stream);
+  if (d.hidden_size == W_ && d.num_encoding_fn_xyz == LX_) {                                 \
+    if (!bf) return launch_forward<W_, LX_, 4, false, 1>(p, stream);                         \
+    return bf16_pt == 1 ? launch_forward<W_, LX_, 4, true, 1>(p, stream)                     \
+                        : launch_forward<W_, LX_, 4, true, 2>(p, stream);                    \
+  }
   DN_CASE(256, 10)
   DN_CASE(128, 10)
   DN_CASE(256, 6)

@@ -15,346 +15,14 @@
 //   * bf16 mode: v_mfma_f32_32x32x16_bf16, 8 waves x 32 points per workgroup, 2 waves / SIMD;
 //     fp32 mode: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), 4 waves x 32 points, 1 wave / SIMD.
 // MFMA-bound: 1,186,816 FLOP per point (D8/W256) against 16 B written per point.
-#include <cstdlib>
-#include <utility>
-
-#include "mlp_layout.h"
+#include "mlp_device.h"
+#include "mlp_internal.h"
 
 namespace dn {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-template <int N, class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
-
-constexpr int kRingPhases = 5;
-constexpr int kSlotBytes = kPhasePieces * kPieceBytes;  // 16 KiB
-constexpr int kRingBytes = kRingPhases * kSlotBytes;    // 80 KiB
-constexpr int kPrefetch = 4;                            // A-fragment pieces read ahead of the MFMA that uses them
-constexpr int kInRows = 10;                             // per-wave input staging rows
-
-template <bool BF16> struct Prec;
-template <> struct Prec<true> {
-  using BPiece = bf16x8;
-  static constexpr int EPP = 8;    // k-values (elements) per lane per piece
-  static constexpr int PPT = 2;    // pieces per 32-row hidden tile
-};
-template <> struct Prec<false> {
-  using BPiece = f32x4;
-  static constexpr int EPP = 4;
-  static constexpr int PPT = 4;
-};
-// Geometry: PT point-tiles (of 32 points) per wave.  bf16 default: PT=1 -> 8 waves x 32 points, two waves per
-// SIMD.  bf16 PT=2 -> 4 waves x 64 points, one wave per SIMD (every A fragment read from LDS feeds two MFMAs;
-// halves the LDS read traffic but a lone wave per SIMD hides no stall - measured 4 % slower).  fp32: PT=1,
-// 4 waves x 32 points, one wave per SIMD.
-template <bool BF16, int PT> constexpr int waves_of() { return (BF16 && PT == 1) ? 8 : 4; }
-
-struct FwdParams {
-  const char* packed;   // [bias region][pieces]
-  int bias_bytes;
-  int total_pieces;
-  int D;
-  unsigned skip_mask;
-  int use_viewdirs;
-  int mode;             // 0: rays + z_vals, 1: pts (+ viewdirs), 2: encoded rows
-  const float* rays;
-  int ray_stride;
-  const float* z;
-  const float* pts;
-  const float* viewdirs;
-  const float* enc;
-  int enc_ld;
-  long long n_points;
-  int S;                // samples per ray (ray = point / S)
-  long long n_tiles;
-  float* out;
-  float fx[16];
-  float fd[8];
-};
-
-// ---- weight pipeline: LDS ring fed by LDS-DMA -------------------------------------------------------
-// Ring of 5 x 16 KiB phases.  At the barrier that opens phase p every wave has waited for its own DMAs of
-// phases <= p+1, so after the barrier phases p AND p+1 are fully landed: the A-fragment read stream (a FIFO of
-// kPrefetch pieces per wave) runs continuously across phase boundaries.  Phases p+2, p+3 stay in flight
-// (counted vmcnt, never 0 in the loop); phase p+4 is issued into the slot phase p-1 just vacated.
-// Extra VMEM ops (input DMAs, the output store) are younger or older than the DMAs a wait must cover and,
-// because VMEM ops retire in order, can only make a counted wait stricter, never weaker.
-template <int WAVES>
-struct Pipe {
-  static constexpr int PER_WAVE = kPhasePieces / WAVES;
-  char* ring;           // LDS
-  unsigned ring_addr;   // its 32-bit LDS byte address (for M0)
-  const char* wsrc;     // global pieces (wave-uniform pointer)
-  unsigned total_bytes; // stream length in bytes
-  unsigned q_issue;     // byte offset of the next phase to DMA (wave-uniform)
-  unsigned slot_wr, slot_nxt;
-  unsigned wave;
-  unsigned pend_src, pend_dst;  // this wave's DMA of the phase being issued (wave-uniform byte offsets)
-  const char* rd_cur;   // LDS read pointers (+ lane*16) of the current and the next phase
-  const char* rd_nxt;
-  unsigned lane16;
-  f32x4 af[kPrefetch];  // A-fragment FIFO: af[pos % kPrefetch] holds piece `pos` when it is consumed
-
-  // DMA of one phase = PER_WAVE consecutive pieces per wave, as ONE opaque asm statement: SGPR-base form of
-  // global_load_lds (32-bit lane offset), M0 saved/restored inside the statement, and a wave-uniform skip
-  // branch *inside* the asm so the compiler sees straight-line code (a C++ branch here splits every phase into
-  // basic blocks and costs dozens of spilled registers).  The instruction offset advances both the global and
-  // the LDS address.  hipcc does not count these in its own waitcnt bookkeeping - the counted waits are ours.
-  __device__ __forceinline__ void dma_phase(unsigned src_off, unsigned dst_off, unsigned go) {
-#ifndef DN_EXP_NODMA
-    // every "s" operand must be provably wave-uniform: readfirstlane them (they are uniform by construction)
-    const unsigned long long src_bits = reinterpret_cast<unsigned long long>(wsrc + src_off);
-    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(src_bits));
-    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(src_bits >> 32));
-    const char* src = reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
-    const unsigned lds = __builtin_amdgcn_readfirstlane(ring_addr + dst_off);
-    go = __builtin_amdgcn_readfirstlane(go);
-    unsigned keep;
-    if constexpr (PER_WAVE == 2) {
-      asm volatile(
-          "s_cmp_lg_u32 %[go], 0\n\t"
-          "s_cbranch_scc0 .Ldn_dma_skip%=\n\t"
-          "s_mov_b32 %[keep], m0\n\t"
-          "s_mov_b32 m0, %[lds]\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %[voff], %[sbase]\n\t"
-          "global_load_lds_dwordx4 %[voff], %[sbase] offset:1024\n\t"
-          "s_mov_b32 m0, %[keep]\n"
-          ".Ldn_dma_skip%=:"
-          : [keep] "=&s"(keep)
-          : [go] "s"(go), [lds] "s"(lds), [voff] "v"(lane16), [sbase] "s"(src)
-          : "memory", "scc");
-    } else {
-      asm volatile(
-          "s_cmp_lg_u32 %[go], 0\n\t"
-          "s_cbranch_scc0 .Ldn_dma_skip%=\n\t"
-          "s_mov_b32 %[keep], m0\n\t"
-          "s_mov_b32 m0, %[lds]\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %[voff], %[sbase]\n\t"
-          "global_load_lds_dwordx4 %[voff], %[sbase] offset:1024\n\t"
-          "global_load_lds_dwordx4 %[voff], %[sbase] offset:2048\n\t"
-          "global_load_lds_dwordx4 %[voff], %[sbase] offset:3072\n\t"
-          "s_mov_b32 m0, %[keep]\n"
-          ".Ldn_dma_skip%=:"
-          : [keep] "=&s"(keep)
-          : [go] "s"(go), [lds] "s"(lds), [voff] "v"(lane16), [sbase] "s"(src)
-          : "memory", "scc");
-    }
-#endif
-  }
-
-  __device__ __forceinline__ void advance_issue() {
-    pend_src = q_issue + wave * (PER_WAVE * kPieceBytes);
-    pend_dst = slot_wr * kSlotBytes + wave * (PER_WAVE * kPieceBytes);
-    q_issue += kSlotBytes;
-    if (q_issue >= total_bytes) q_issue = 0;
-    slot_wr = (slot_wr + 1 == kRingPhases) ? 0 : slot_wr + 1;
-  }
-
-  __device__ __forceinline__ void issue_phase() {  // prologue only
-    advance_issue();
-    dma_phase(pend_src, pend_dst, 1u);
-  }
-
-  // Called at every 16-piece boundary of the (compile-time laid out) consumption sequence.
-  // With two waves per SIMD (bf16 build) the DMA issue is split: waves 0-3 issue right after the barrier, waves
-  // 4-7 eight pieces later (mid_phase), so a wave's DMA-issue time (an LDS-DMA costs ~60-180 issue cycles) is
-  // covered by its SIMD partner's MFMAs instead of both stalling the matrix pipe together.
-  __device__ __forceinline__ void phase_begin() {
-    // (kRingPhases-3) younger phases may stay outstanding; lgkmcnt(0): this wave's LDS reads of the previous
-    // phase are complete before its slot is recycled (and the FIFO entries for this phase have arrived).
-    static_assert(kRingPhases == 5, "the counted waits below assume two younger phases in flight");
-#ifdef DN_EXP_SHALLOW  // ablation: only one younger phase in flight
-    if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-#else
-    if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-#endif
-    __builtin_amdgcn_s_barrier();
-    advance_issue();
-    dma_phase(pend_src, pend_dst, (WAVES == 4 || wave < 4) ? 1u : 0u);
-    rd_cur = rd_nxt;
-    slot_nxt = (slot_nxt + 1 == kRingPhases) ? 0 : slot_nxt + 1;
-    rd_nxt = ring + slot_nxt * kSlotBytes + lane16;
-  }
-
-  __device__ __forceinline__ void mid_phase() {
-    if constexpr (WAVES == 8) dma_phase(pend_src, pend_dst, wave >= 4 ? 1u : 0u);
-  }
-
-  // after consuming piece POS (position within the 16-piece phase), read piece POS + kPrefetch into its FIFO slot
-  template <int POS>
-  __device__ __forceinline__ void prefetch() {
-    constexpr int q = (POS % kPhasePieces) + kPrefetch;
-    const char* base = (q < kPhasePieces) ? rd_cur : rd_nxt;
-#ifndef DN_EXP_NOREAD
-    af[POS % kPrefetch] = *reinterpret_cast<const f32x4*>(base + (q % kPhasePieces) * kPieceBytes);
-#endif
-  }
-};
-
-template <bool BF16>
-__device__ __forceinline__ f32x16 mma_piece(f32x16 acc, f32x4 a_raw, typename Prec<BF16>::BPiece b) {
-  if constexpr (BF16) {
-    const bf16x8 a = __builtin_bit_cast(bf16x8, a_raw);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-  } else {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_raw[0], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_raw[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_raw[2], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_raw[3], b[3], acc, 0, 0, 0);
-    return acc;
-  }
-}
-
-// One GEMM stage: NT_OUT output tiles, KH hidden pieces + KP positional-encoding pieces per tile, for the PT
-// point-tiles this wave owns (each A fragment is read once and feeds PT MFMAs).
-// Each tile's K-reduction completes on its own, so only PT 32x32 accumulator tiles are live at a time; `emit`
-// consumes them (ReLU + convert into the next stage's B pieces, or pick the output rows) while the next tile's
-// MFMAs are already being issued.  POS0 = piece position (mod 16) at which the stage starts; phase boundaries
-// (counted vmcnt + barrier + next DMA) are compile-time positions in the unrolled sequence.
-template <bool BF16, int PT, int NT_OUT, int KH, int KP, int POS0, class PipeT, class BH, class BP, class Emit>
-__device__ __forceinline__ void run_stage(PipeT& pipe, const BH& bh /* [PT][KH] */, BP&& bp /* (t, k) -> PE piece */,
-                                          const char* bias_lds /* this lane-half's 64 B of tile 0 */, Emit&& emit) {
-  constexpr int KT = KH + KP;
-  static_for<NT_OUT>([&](auto nt_c) {
-    constexpr int nt = decltype(nt_c)::value;
-    const f32x4* bptr = reinterpret_cast<const f32x4*>(bias_lds + nt * 128);
-    const f32x4 b0 = bptr[0], b1 = bptr[1], b2 = bptr[2], b3 = bptr[3];
-    f32x16 a[PT];
-#pragma unroll
-    for (int t = 0; t < PT; ++t) {
-      a[t][0] = b0[0]; a[t][1] = b0[1]; a[t][2] = b0[2]; a[t][3] = b0[3];
-      a[t][4] = b1[0]; a[t][5] = b1[1]; a[t][6] = b1[2]; a[t][7] = b1[3];
-      a[t][8] = b2[0]; a[t][9] = b2[1]; a[t][10] = b2[2]; a[t][11] = b2[3];
-      a[t][12] = b3[0]; a[t][13] = b3[1]; a[t][14] = b3[2]; a[t][15] = b3[3];
-    }
-    static_for<KT>([&](auto k_c) {
-      constexpr int k = decltype(k_c)::value;
-      constexpr int pos = POS0 + nt * KT + k;
-      if constexpr (pos % kPhasePieces == 0) pipe.phase_begin();
-      if constexpr (pos % kPhasePieces == kPhasePieces / 2) pipe.mid_phase();
-      const f32x4 araw = pipe.af[pos % kPrefetch];
-      static_for<PT>([&](auto t_c) {
-        constexpr int t = decltype(t_c)::value;
-        if constexpr (k < KH) a[t] = mma_piece<BF16>(a[t], araw, bh[t][k]);
-        else a[t] = mma_piece<BF16>(a[t], araw, bp(t, k - KH));
-      });
-      pipe.template prefetch<pos>();
-      // pin the interleave: the MFMAs of this piece, then the one LDS read that refills its FIFO slot
-      __builtin_amdgcn_sched_group_barrier(0x008, (BF16 ? 1 : 4) * PT, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    });
-    // region boundary BEFORE the epilogue: emit(nt)'s VALU work may overlap tile nt+1's MFMAs, but whole tiles
-    // are not interleaved (that would keep several accumulator tiles live and spill)
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<PT>([&](auto t_c) { emit(nt_c, t_c, a[decltype(t_c)::value]); });
-  });
-}
-
-// accumulator tile -> the next stage's B pieces (in the register-resident chain), optional ReLU.
-// bf16: convert first, then ReLU on the packed pairs as a signed-int16 max with 0 (a negative bf16 has its
-// sign bit set, i.e. is a negative int16; -0.0 -> +0.0): 4 v_pk_max_i16 instead of 8 v_max_f32 per piece.
-template <bool BF16, bool RELU, int S>
-__device__ __forceinline__ typename Prec<BF16>::BPiece make_piece(const f32x16& acc) {
-  using P = Prec<BF16>;
-  typename P::BPiece piece;
-  if constexpr (BF16) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) piece[e] = static_cast<__bf16>(acc[S * 8 + e]);
-    if constexpr (RELU) {
-      typedef short s16x8 __attribute__((ext_vector_type(8)));
-      s16x8 bits = __builtin_bit_cast(s16x8, piece);
-      const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-      bits = __builtin_elementwise_max(bits, zero);
-      piece = __builtin_bit_cast(typename P::BPiece, bits);
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) piece[e] = RELU ? fmaxf(acc[S * 4 + e], 0.0f) : acc[S * 4 + e];
-  }
-  return piece;
-}
-
-template <bool BF16, bool RELU, int NT, class BO>
-__device__ __forceinline__ void emit_pieces(const f32x16& acc, BO& bo) {
-  using P = Prec<BF16>;
-  static_for<P::PPT>([&](auto s_c) {
-    constexpr int s = decltype(s_c)::value;
-    bo[NT * P::PPT + s] = make_piece<BF16, RELU, s>(acc);
-  });
-}
-
-// ---- positional encoding straight into B-piece layout -------------------------------------------------
-// Slot u of this lane-half (mlp_layout.h pe_slot_col): u < 6*(L/2): sin/cos of this half's frequencies;
-// then identity (half 0: x, y; half 1: z); rest zero padding.
-template <bool BF16, int L, int NPIECES, class BP>
-__device__ __forceinline__ void encode_pieces(const float (&x)[3], const float* freqs, int h, BP& bp) {
-  using P = Prec<BF16>;
-  constexpr int NF = L / 2;
-  float sv[NF][3], cv[NF][3];
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    const float fr = h ? freqs[NF + f] : freqs[f];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float arg = x[c] * fr;
-      if constexpr (BF16) {
-        // hardware sin/cos take revolutions in [-256, 256]: reduce with fract first (bf16 output precision)
-        const float rev = __builtin_amdgcn_fractf(arg * 0.15915494309189535f);
-        sv[f][c] = __builtin_amdgcn_sinf(rev);
-        cv[f][c] = __builtin_amdgcn_cosf(rev);
-      } else {
-        sincosf(arg, &sv[f][c], &cv[f][c]);
-      }
-    }
-  }
-  static_for<NPIECES>([&](auto p_c) {
-    constexpr int p = decltype(p_c)::value;
-    typename P::BPiece piece;
-    static_for<P::EPP>([&](auto e_c) {
-      constexpr int e = decltype(e_c)::value;
-      constexpr int u = p * P::EPP + e;
-      float v;
-      if constexpr (u < 6 * NF) v = ((u % 6) < 3) ? sv[u / 6][u % 3] : cv[u / 6][u % 3];
-      else if constexpr (u == 6 * NF) v = h ? x[2] : x[0];
-      else if constexpr (u == 6 * NF + 1) v = h ? 0.0f : x[1];
-      else v = 0.0f;
-      if constexpr (BF16) piece[e] = static_cast<__bf16>(v); else piece[e] = v;
-    });
-    bp[p] = piece;
-  });
-}
-
-// Encoded-rows input (FlexibleNeRFModel.forward(x) call surface): gather this lane's slots from x.
-template <bool BF16, int L, int NPIECES, class BP>
-__device__ __forceinline__ void gather_pieces(const float* row, int h, BP& bp) {
-  using P = Prec<BF16>;
-  static_for<NPIECES>([&](auto p_c) {
-    constexpr int p = decltype(p_c)::value;
-    typename P::BPiece piece;
-#pragma unroll
-    for (int e = 0; e < P::EPP; ++e) {
-      const int col = pe_slot_col(L, h, p * P::EPP + e);
-      const float v = (col >= 0) ? row[col] : 0.0f;
-      if constexpr (BF16) piece[e] = static_cast<__bf16>(v); else piece[e] = v;
-    }
-    bp[p] = piece;
-  });
-}
-
-template <int W, int LX, int LD, bool BF16, int PT>
+// SAVE = training forward: every stage's output pieces (and both encodings) are also written to `p.act` in the
+// wave-native piece layout, plus one 128-bit ReLU mask word per lane per masked stage to `p.masks`.
+template <int W, int LX, int LD, bool BF16, int PT, bool SAVE>
 __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2 : 1)) void mlp_forward_kernel(FwdParams p) {
   using P = Prec<BF16>;
   using BPiece = typename P::BPiece;
@@ -499,6 +167,54 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
     }
     auto pe_xyz = [&](int t, int k) { return *reinterpret_cast<const BPiece*>(pex + (t * KXP + k) * kPieceBytes); };
     auto no_pe = [&](int, int) { return BPiece{}; };
+    // training forward: where this wave's 32-point tile t keeps its saved pieces / mask words
+    auto act_ptr = [&](int t, int slot) {
+      const long long tile32 = (tile * WAVES + wave) * PT + t;
+      return p.act + ((tile32 * p.act_pieces + slot) * 64 + lane) * 16;
+    };
+    auto save_pieces = [&](auto nt_c, int t, int slot0, const BPiece* pieces) {
+      if constexpr (SAVE) {
+        constexpr int nt = decltype(nt_c)::value;
+#pragma unroll
+        for (int s2 = 0; s2 < P::PPT; ++s2)
+          *reinterpret_cast<BPiece*>(act_ptr(t, slot0 + nt * P::PPT + s2)) = pieces[nt * P::PPT + s2];
+      }
+    };
+    unsigned maskw[PT][4];
+    auto mask_clear = [&]() {
+#pragma unroll
+      for (int t = 0; t < PT; ++t) { maskw[t][0] = 0u; maskw[t][1] = 0u; maskw[t][2] = 0u; maskw[t][3] = 0u; }
+    };
+    auto mask_tile = [&](auto nt_c, int t, const f32x16& acc) {   // bit (nt*16 + r) = acc[r] > 0
+      if constexpr (SAVE) {
+        constexpr int nt = decltype(nt_c)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) maskw[t][(nt * 16 + r) / 32] |= (acc[r] > 0.0f) ? (1u << ((nt * 16 + r) % 32)) : 0u;
+      }
+    };
+    auto mask_store = [&](int word) {
+      if constexpr (SAVE) {
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+          const long long tile32 = (tile * WAVES + wave) * PT + t;
+          uint4 v = make_uint4(maskw[t][0], maskw[t][1], maskw[t][2], maskw[t][3]);
+          *reinterpret_cast<uint4*>(p.masks + ((tile32 * p.mask_words + word) * 64 + lane) * 16) = v;
+        }
+      }
+    };
+    if constexpr (SAVE) {
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+#pragma unroll
+        for (int k = 0; k < KXP; ++k) *reinterpret_cast<BPiece*>(act_ptr(t, p.slot_xyz + k)) = pe_xyz(t, k);
+        if (p.use_viewdirs) {
+#pragma unroll
+          for (int k = 0; k < KDP; ++k)
+            *reinterpret_cast<BPiece*>(act_ptr(t, p.slot_dir + k)) =
+                *reinterpret_cast<const BPiece*>(ped + (t * KDP + k) * kPieceBytes);
+        }
+      }
+    }
 
     BPiece ba[PT][KH], bb[PT][KH];
     BPiece none[PT][1];
@@ -506,17 +222,24 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
     // One trunk layer: layers_xyz[i] on (cat(x, xyz) when it is a skip layer) -> W, ReLU (models.py:239-246)
     auto trunk_layer = [&](int i, const BPiece (&bin)[PT][KH], BPiece (&bout)[PT][KH]) {
       auto emit = [&](auto nt_c, auto t_c, const f32x16& acc) {
-        emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bout[decltype(t_c)::value]);
+        constexpr int t = decltype(t_c)::value;
+        emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bout[t]);
+        save_pieces(nt_c, t, p.slot_trunk0 + i * KH, bout[t]);
+        mask_tile(nt_c, t, acc);
       };
+      mask_clear();
       if ((p.skip_mask >> i) & 1u)
         run_stage<BF16, PT, NT, KH, KXP, 0>(pipe, bin, pe_xyz, bias_half + bias_tile * 128, emit);
       else
         run_stage<BF16, PT, NT, KH, 0, 0>(pipe, bin, no_pe, bias_half + bias_tile * 128, emit);
+      mask_store(i);
       bias_tile += NT;
     };
     // ---- layer1: xyz encoding -> W, no activation (models.py:238) ----
     run_stage<BF16, PT, NT, 0, KXP, 0>(pipe, none, pe_xyz, bias_half, [&](auto nt_c, auto t_c, const f32x16& acc) {
-      emit_pieces<BF16, false, decltype(nt_c)::value>(acc, ba[decltype(t_c)::value]);
+      constexpr int t = decltype(t_c)::value;
+      emit_pieces<BF16, false, decltype(nt_c)::value>(acc, ba[t]);
+      save_pieces(nt_c, t, p.slot_layer1, ba[t]);
     });
     bias_tile += NT;
     // ---- trunk, two layers per iteration so the activations ping-pong between two register sets ----
@@ -541,19 +264,29 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
                                               out4[decltype(t_c)::value][3] = acc[0];  // row 0: lanes 0..31, reg 0
                                             });
       constexpr int POS_F = (POS_A + KH) % kPhasePieces;
+      mask_clear();
       run_stage<BF16, PT, NT, KH, 0, POS_F>(pipe, ba, no_pe, bias_half + (bias_tile + 1) * 128,
                                              [&](auto nt_c, auto t_c, const f32x16& acc) {
-                                               emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bb[decltype(t_c)::value]);
+                                               constexpr int t = decltype(t_c)::value;
+                                               emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bb[t]);
+                                               save_pieces(nt_c, t, p.slot_feat, bb[t]);
+                                               mask_tile(nt_c, t, acc);
                                              });
+      mask_store(p.D - 1);
       bias_tile += NT + 1;
       // ---- layers_dir[0] on cat(feat, view) -> W/2, ReLU (models.py:250-252) ----
       constexpr int POS_D = (POS_F + NT * KH) % kPhasePieces;
       BPiece bg[PT][KH / 2];
       auto pe_dir = [&](int t, int k) { return *reinterpret_cast<const BPiece*>(ped + (t * KDP + k) * kPieceBytes); };
+      mask_clear();
       run_stage<BF16, PT, NT / 2, KH, KDP, POS_D>(pipe, bb, pe_dir, bias_half + bias_tile * 128,
                                                    [&](auto nt_c, auto t_c, const f32x16& acc) {
-                                                     emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bg[decltype(t_c)::value]);
+                                                     constexpr int t = decltype(t_c)::value;
+                                                     emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bg[t]);
+                                                     save_pieces(nt_c, t, p.slot_dirout, bg[t]);
+                                                     mask_tile(nt_c, t, acc);
                                                    });
+      mask_store(p.D);
       bias_tile += NT / 2;
       // ---- fc_rgb (models.py:253) ----
       constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % kPhasePieces;
@@ -570,6 +303,7 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
                                           constexpr int t = decltype(t_c)::value;
                                           out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2]; out4[t][3] = acc[3];
                                         });
+      if constexpr (KH % kPhasePieces != 0) pipe.template skip<KH % kPhasePieces, kPhasePieces - KH % kPhasePieces>();
     }
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
@@ -585,13 +319,9 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
 }
 
 // ---- pack kernel: nn.Linear tensors -> bias tiles + MFMA-A piece stream ---------------------------------
-struct PackPtrs {
-  const float* w[kMaxStages];
-  const float* b[kMaxStages];
-};
 
 template <bool BF16>
-__global__ void pack_kernel(NetLayout L, PackPtrs ptrs, char* __restrict__ packed) {
+__global__ void pack_kernel(NetLayout L, PackPtrs ptrs, char* __restrict__ packed) {  // also used by mlp_train.hip
   using P = Prec<BF16>;
   const int KX = round_up(3 + 6 * L.LX, 16), KD = round_up(3 + 6 * L.LD, 16);
   (void)KX; (void)KD;
@@ -631,7 +361,28 @@ __global__ void pack_kernel(NetLayout L, PackPtrs ptrs, char* __restrict__ packe
     while (s + 1 < L.n_stages && L.st[s + 1].piece0 <= piece) ++s;
     const StageDesc& st = L.st[s];
     const int rel = piece - st.piece0;
-    if (rel < st.n_tiles * st.pieces_per_tile) {
+    if (st.transposed) {
+      // backward-data stage: A[row][k] = W[k][row0 + row]; k runs over the forward layer's outputs in accumulator
+      // order (hidden pieces) and then over one optional "custom" piece (half hh, element e -> k = hh*EPP + e)
+      if (rel < st.n_tiles * st.pieces_per_tile) {
+        const int ts = rel / st.pieces_per_tile;
+        const int k = rel % st.pieces_per_tile;
+        const int kh = st.hidden_in / (2 * P::EPP);
+        const int row = ts * 32 + i;
+        if (row < st.n_real) {
+          if (k < kh) {
+            const int kout = (k / P::PPT) * 32 + acc_row((k % P::PPT) * P::EPP + e, hh);
+            v = ptrs.w[st.src][static_cast<long long>(kout) * st.ld + st.col_hidden0 + row];
+          } else {
+            const int kc = hh * P::EPP + e;
+            if (kc < st.custom_k) {
+              const int srcw = st.src2 >= 0 ? st.src2 : st.src;
+              v = ptrs.w[srcw][static_cast<long long>(kc) * st.ld + st.col_hidden0 + row];
+            }
+          }
+        }
+      }
+    } else if (rel < st.n_tiles * st.pieces_per_tile) {
       const int ts = rel / st.pieces_per_tile;
       const int k = rel % st.pieces_per_tile;
       const int kh = st.hidden_in / (2 * P::EPP);  // hidden pieces
@@ -660,9 +411,9 @@ __global__ void pack_kernel(NetLayout L, PackPtrs ptrs, char* __restrict__ packe
   }
 }
 
-template <int W, int LX, int LD, bool BF16, int PT>
+template <int W, int LX, int LD, bool BF16, int PT, bool SAVE = false>
 static int launch_forward(FwdParams p, hipStream_t stream) {
-  auto kern = mlp_forward_kernel<W, LX, LD, BF16, PT>;
+  auto kern = mlp_forward_kernel<W, LX, LD, BF16, PT, SAVE>;
   constexpr int WAVES = waves_of<BF16, PT>();
   constexpr int PTS_PER_WG = WAVES * 32 * PT;
   constexpr int KXP = round_up(3 + 6 * LX, 16) / (2 * Prec<BF16>::EPP);
@@ -683,11 +434,19 @@ static int launch_forward(FwdParams p, hipStream_t stream) {
   return check_launch("mlp_forward");
 }
 
-static int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStream_t stream) {
+int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStream_t stream) {
   const bool bf = precision == DN_PREC_BF16;
   // bf16 geometry: PT=1 (8 waves x 32 points, two waves per SIMD) measured fastest (1327 vs 1277 TFLOP/s for
   // PT=2 = 4 waves x 64 points, one wave per SIMD); DEXNERF_BF16_PT=2 selects the latter for experiments
   static const int bf16_pt = [] { const char* e = getenv("DEXNERF_BF16_PT"); return (e && atoi(e) == 2) ? 2 : 1; }();
+  if (p.act != nullptr) {  // training forward: LX=10 nets, PT=1
+    if (d.num_encoding_fn_xyz == 10 && d.hidden_size == 256)
+      return bf ? launch_forward<256, 10, 4, true, 1, true>(p, stream) : launch_forward<256, 10, 4, false, 1, true>(p, stream);
+    if (d.num_encoding_fn_xyz == 10 && d.hidden_size == 128)
+      return bf ? launch_forward<128, 10, 4, true, 1, true>(p, stream) : launch_forward<128, 10, 4, false, 1, true>(p, stream);
+    set_error("mlp_forward(train): no kernel instance for W=%d L_xyz=%d", d.hidden_size, d.num_encoding_fn_xyz);
+    return DN_E_UNSUPPORTED;
+  }
 #define DN_CASE(W_, LX_)                                                                     \
   if (d.hidden_size == W_ && d.num_encoding_fn_xyz == LX_) {                                 \
     if (!bf) return launch_forward<W_, LX_, 4, false, 1>(p, stream);                         \
@@ -705,7 +464,7 @@ static int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, h
 
 void fill_freqs(float* f, int num_fns, int log_sampling);  // rays_sampling.hip
 
-static int setup_params(const dn_mlp_desc* desc, int precision, const void* packed, FwdParams* p) {
+int setup_params(const dn_mlp_desc* desc, int precision, const void* packed, FwdParams* p) {
   int rc = validate_desc(desc, precision);
   if (rc) return rc;
   NetLayout L;
@@ -720,6 +479,14 @@ static int setup_params(const dn_mlp_desc* desc, int precision, const void* pack
   fill_freqs(p->fx, desc->num_encoding_fn_xyz, desc->log_sampling_xyz);
   if (desc->use_viewdirs) fill_freqs(p->fd, desc->num_encoding_fn_dir, desc->log_sampling_dir);
   return 0;
+}
+
+int launch_pack(const NetLayout& L, const PackPtrs& ptrs, void* packed, int precision, hipStream_t stream) {
+  if (precision == DN_PREC_BF16)
+    hipLaunchKernelGGL(pack_kernel<true>, dim3(512), dim3(256), 0, stream, L, ptrs, static_cast<char*>(packed));
+  else
+    hipLaunchKernelGGL(pack_kernel<false>, dim3(512), dim3(256), 0, stream, L, ptrs, static_cast<char*>(packed));
+  return check_launch("mlp_pack");
 }
 
 }  // namespace dn
@@ -748,11 +515,7 @@ extern "C" int dn_mlp_pack(const dn_mlp_desc* desc, int precision, const float* 
     ptrs.w[i] = h_weights[i];
     ptrs.b[i] = h_biases[i];
   }
-  if (precision == DN_PREC_BF16)
-    hipLaunchKernelGGL(pack_kernel<true>, dim3(512), dim3(256), 0, as_stream(stream), L, ptrs, static_cast<char*>(packed));
-  else
-    hipLaunchKernelGGL(pack_kernel<false>, dim3(512), dim3(256), 0, as_stream(stream), L, ptrs, static_cast<char*>(packed));
-  return check_launch("dn_mlp_pack");
+  return launch_pack(L, ptrs, packed, precision, as_stream(stream));
 }
 
 extern "C" int dn_run_network(const dn_mlp_desc* desc, int precision, const void* packed, const float* pts,

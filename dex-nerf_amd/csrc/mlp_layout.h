@@ -51,6 +51,10 @@ struct StageDesc {
   int32_t piece0;       // first piece of this stage in the stream
   int32_t bias0;        // first bias tile of this stage
   int32_t pieces_per_tile;
+  // backward (dX) stages: A[i][k] = W[k][row0 + i] (the nn.Linear weight read transposed); `hidden_in` then counts
+  // the forward layer's OUTPUT features (the k dimension), n_real its hidden INPUT features (the rows).
+  int32_t transposed;
+  int32_t custom_k;     // extra "custom" input piece: rows of src2 (fc_alpha: 1) or of src itself (fc_rgb: 3)
 };
 
 struct NetLayout {
@@ -106,6 +110,87 @@ inline int build_layout(const dn_mlp_desc& d, int precision, NetLayout* out) {
   L.total_pieces = round_up(piece, kPhasePieces);
   L.total_bias_tiles = bias;
   L.bias_bytes = round_up(bias * 128, 1024);
+  return 0;
+}
+
+// Saved-activation slots of the training forward (units: pieces of 1 KiB per 32-point tile), in this order:
+//   [xyz PE | dir PE | layer1 out | trunk 0..D-2 out | fc_feat out | layers_dir.0 out]
+// and one 16-byte ReLU bit-mask word per lane per masked stage (trunk 0..D-2, fc_feat, layers_dir.0).
+struct TrainLayout {
+  int32_t kpp, epp, ppt;
+  int32_t kxp, kdp, kh;             // pieces: xyz PE, dir PE, a W-wide hidden vector
+  int32_t act_pieces;               // saved forward pieces per 32-point tile
+  int32_t slot_xyz, slot_dir, slot_layer1, slot_trunk0, slot_feat, slot_dirout;
+  int32_t mask_words;               // 16-byte mask words per lane per tile: (D-1) trunk + feat + dirout
+  int32_t grad_pieces;              // saved dL/d(pre-activation) pieces per tile
+  int32_t gslot_dirout, gslot_feat, gslot_trunk0, gslot_layer1;  // gslot_trunk0 + i*kh for layers_xyz[i]
+};
+
+inline void build_train_layout(const dn_mlp_desc& d, int precision, TrainLayout* t) {
+  const bool bf = precision == DN_PREC_BF16;
+  t->kpp = bf ? 16 : 8; t->epp = bf ? 8 : 4; t->ppt = bf ? 2 : 4;
+  const int W = d.hidden_size, D = d.num_layers;
+  t->kxp = round_up(3 + 6 * d.num_encoding_fn_xyz, 16) / t->kpp;
+  t->kdp = d.use_viewdirs ? round_up(3 + 6 * d.num_encoding_fn_dir, 16) / t->kpp : 0;
+  t->kh = W / t->kpp;
+  int s = 0;
+  t->slot_xyz = s; s += t->kxp;
+  t->slot_dir = s; s += t->kdp;
+  t->slot_layer1 = s; s += t->kh;
+  t->slot_trunk0 = s; s += (D - 1) * t->kh;
+  t->slot_feat = s; s += d.use_viewdirs ? t->kh : 0;
+  t->slot_dirout = s; s += d.use_viewdirs ? t->kh / 2 : 0;
+  t->act_pieces = s;
+  t->mask_words = (D - 1) + (d.use_viewdirs ? 2 : 0);
+  int g = 0;
+  t->gslot_dirout = g; g += d.use_viewdirs ? t->kh / 2 : 0;
+  t->gslot_feat = g; g += d.use_viewdirs ? t->kh : 0;
+  t->gslot_trunk0 = g; g += (D - 1) * t->kh;
+  t->gslot_layer1 = g; g += t->kh;
+  t->grad_pieces = g;
+}
+
+// Backward-data stream (dL/dX chain), stages in the order the backward kernel consumes them:
+//   fc_rgb^T, layers_dir.0^T (feat rows only), [fc_feat^T | fc_alpha^T], layers_xyz[D-2..0]^T (hidden rows only).
+// (no-viewdirs nets: fc_out^T, then the trunk.)  No bias tiles.
+inline int build_backward_layout(const dn_mlp_desc& d, int precision, NetLayout* out) {
+  const int kpp = (precision == DN_PREC_BF16) ? 16 : 8;
+  const int W = d.hidden_size, D = d.num_layers;
+  const int DX = 3 + 6 * d.num_encoding_fn_xyz, DD = 3 + 6 * d.num_encoding_fn_dir;
+  NetLayout& L = *out;
+  L = NetLayout{};
+  L.W = W; L.LX = d.num_encoding_fn_xyz; L.LD = d.num_encoding_fn_dir; L.D = D; L.use_viewdirs = d.use_viewdirs;
+  int piece = 0, s = 0;
+  // n_rows: forward hidden-input width (rows of the transposed weight); k_hidden: forward output width fed by
+  // accumulator pieces; custom: number of extra k columns taken from `src2` (or from `src` when k_hidden == 0)
+  auto add = [&](int n_rows, int k_hidden, int custom, int src, int src2, int ld, int row0) {
+    StageDesc& t = L.st[s++];
+    t = StageDesc{};
+    t.n_tiles = n_rows / 32; t.hidden_in = k_hidden; t.pe_kind = 0; t.src = src; t.src2 = src2;
+    t.n_real = n_rows; t.ld = ld; t.col_hidden0 = row0; t.col_pe0 = 0; t.first_tile2 = -1;
+    t.transposed = 1; t.custom_k = custom;
+    t.pieces_per_tile = k_hidden / kpp + (custom > 0 ? 1 : 0);
+    t.piece0 = piece; t.bias0 = 0;
+    piece += t.n_tiles * t.pieces_per_tile;
+  };
+  for (int i = 0; i < D - 1; ++i)
+    if ((i % d.skip_connect_every == 0) && i > 0 && i != D - 1) L.skip_mask |= (1u << i);
+  if (d.use_viewdirs) {
+    const int i_dir = D, i_alpha = D + 1, i_rgb = D + 2, i_feat = D + 3;
+    add(W / 2, 0, 3, i_rgb, -1, W / 2, 0);            // d g      = fc_rgb^T d rgb
+    add(W, W / 2, 0, i_dir, -1, W + DD, 0);           // d feat   = layers_dir.0[:, :W]^T d dirpre
+    add(W, W, 1, i_feat, i_alpha, W, 0);              // d h      = fc_feat^T d featpre + fc_alpha^T d alpha
+  } else {
+    add(W, 0, 4, D, -1, W, 0);                        // d h      = fc_out^T d out
+  }
+  for (int i = D - 2; i >= 0; --i) {
+    const bool wide = (L.skip_mask >> i) & 1u;
+    add(W, W, 0, 1 + i, -1, wide ? W + DX : W, 0);    // d x_i    = layers_xyz[i][:, :W]^T d pre_i
+  }
+  L.n_stages = s;
+  L.total_pieces = round_up(piece, kPhasePieces);
+  L.total_bias_tiles = 0;
+  L.bias_bytes = 0;
   return 0;
 }
 

@@ -1,0 +1,354 @@
+// Training kernels of the fused network path: the backward-data (dL/dX) chain and the native->plain unpack.
+//
+// The training forward is mlp_forward_kernel<..., SAVE=true> (mlp_fused.hip): it keeps every stage's output
+// pieces and a 128-bit ReLU mask word per lane per stage.  The backward chain below is the same register-resident
+// MFMA chain run on the TRANSPOSED weight stream: for 32 points per wave,
+//     dX^T[K x 32] = W^T[K x N] . dY^T[N x 32],   dY = dX_next (.) relu'(Y)
+// so the gradient tile produced by one stage's MFMAs is (after masking) the B operand of the next stage, exactly
+// like the activations in the forward.  Every masked gradient dL/d(pre-activation) is written out once in the
+// wave-native piece layout; dW/db are formed from those and the saved activations (dn_mlp_unpack + GEMM).
+// MFMA-bound like the forward: 2 x hidden MACs per point, 16-32 B/point/stage written.
+#include "mlp_internal.h"
+
+namespace dn {
+
+struct BwdParams {
+  const char* packed;      // backward (transposed) piece stream, no bias region
+  int total_pieces;
+  int D;
+  int use_viewdirs;
+  const float* g_out;      // (P,4) dL/d[r,g,b,sigma] of the raw radiance field
+  const char* masks;       // ReLU mask words from the training forward
+  int mask_words;
+  long long n_points;
+  long long n_tiles;
+  char* grads;             // [tile32][grad_pieces][64][16 B]
+  int grad_pieces;
+  int gslot_dirout, gslot_feat, gslot_trunk0, gslot_layer1;
+};
+
+template <int W, bool BF16>
+__global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void mlp_backward_kernel(BwdParams p) {
+  using P = Prec<BF16>;
+  using BPiece = typename P::BPiece;
+  constexpr int PT = 1;
+  constexpr int NT = W / 32;
+  constexpr int KH = NT * P::PPT;
+  constexpr int WAVES = waves_of<BF16, 1>();
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5;
+  const int j = lane & 31;
+
+  Pipe<WAVES> pipe;
+  pipe.ring = ring;
+  pipe.ring_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)ring));
+  pipe.lane16 = lane * 16;
+  pipe.wsrc = p.packed;
+  pipe.total_bytes = static_cast<unsigned>(p.total_pieces) * kPieceBytes;
+  pipe.q_issue = 0;
+  pipe.slot_wr = 0;
+  pipe.wave = wave;
+#pragma unroll
+  for (int ph = 0; ph < kRingPhases - 1; ++ph) pipe.issue_phase();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  pipe.slot_nxt = 0;
+  pipe.rd_cur = ring + lane * 16;
+  pipe.rd_nxt = ring + lane * 16;
+#pragma unroll
+  for (int e = 0; e < kPrefetch; ++e) pipe.af[e] = *reinterpret_cast<const f32x4*>(pipe.rd_nxt + e * kPieceBytes);
+
+  for (long long tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    const long long tile32 = tile * WAVES + wave;
+    long long pt = tile32 * 32 + j;
+    if (pt >= p.n_points) pt = p.n_points - 1;  // clamped lanes recompute a valid point; their stores hit padding tiles
+    const f32x4 g = *reinterpret_cast<const f32x4*>(p.g_out + pt * 4);
+    const char* mask_base = p.masks + (tile32 * p.mask_words * 64 + lane) * 16;
+    auto load_mask = [&](int word) { return *reinterpret_cast<const uint4*>(mask_base + static_cast<long long>(word) * 1024); };
+    char* grad_base = p.grads + (tile32 * p.grad_pieces * 64 + lane) * 16;
+
+    // masked gradient tile -> next stage's B pieces + one store per piece
+    auto emit_grad = [&](auto nt_c, const f32x16& acc_in, const uint4* mw, BPiece* bout, int gslot) {
+      constexpr int nt = decltype(nt_c)::value;
+      f32x16 acc = acc_in;
+      if (mw != nullptr) {
+        const unsigned words[4] = {mw->x, mw->y, mw->z, mw->w};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool on = (words[(nt * 16 + r) / 32] >> ((nt * 16 + r) % 32)) & 1u;
+          acc[r] = on ? acc[r] : 0.0f;
+        }
+      }
+      static_for<P::PPT>([&](auto s_c) {
+        constexpr int s = decltype(s_c)::value;
+        const BPiece piece = make_piece<BF16, false, s>(acc);
+        bout[nt * P::PPT + s] = piece;
+        *reinterpret_cast<BPiece*>(grad_base + static_cast<long long>(gslot + nt * P::PPT + s) * 1024) = piece;
+      });
+    };
+
+    BPiece ba[PT][KH], bb[PT][KH];
+    BPiece none[PT][1];
+    auto no_pe = [&](int, int) { return BPiece{}; };
+    if (p.use_viewdirs) {
+      // custom input pieces: element (half 0, e) carries k = e
+      BPiece crgb{}, calpha{};
+      if (h == 0) {
+        if constexpr (BF16) {
+          crgb[0] = static_cast<__bf16>(g[0]); crgb[1] = static_cast<__bf16>(g[1]); crgb[2] = static_cast<__bf16>(g[2]);
+          calpha[0] = static_cast<__bf16>(g[3]);
+        } else {
+          crgb[0] = g[0]; crgb[1] = g[1]; crgb[2] = g[2];
+          calpha[0] = g[3];
+        }
+      }
+      // ---- d g = fc_rgb^T d rgb, masked by relu'(layers_dir.0 out) ----
+      uint4 mw = load_mask(p.D);
+      uint4 mw_next = load_mask(p.D - 1);
+      auto c_rgb = [&](int, int) { return crgb; };
+      run_stage<BF16, PT, NT / 2, 0, 1, 0, false>(pipe, none, c_rgb, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
+        emit_grad(nt_c, acc, &mw, ba[0], p.gslot_dirout);
+      });
+      // ---- d feat = layers_dir.0[:, :W]^T d dirpre, masked by relu'(fc_feat out) ----
+      constexpr int P1 = (NT / 2) % kPhasePieces;
+      mw = mw_next;
+      mw_next = load_mask(p.D - 2);
+      run_stage<BF16, PT, NT, KH / 2, 0, P1, false>(pipe, ba, no_pe, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
+        emit_grad(nt_c, acc, &mw, bb[0], p.gslot_feat);
+      });
+      // ---- d h = fc_feat^T d featpre + fc_alpha^T d alpha, masked by relu'(layers_xyz[D-2] out) ----
+      constexpr int P2 = (P1 + NT * (KH / 2)) % kPhasePieces;
+      mw = mw_next;
+      auto c_alpha = [&](int, int) { return calpha; };
+      run_stage<BF16, PT, NT, KH, 1, P2, false>(pipe, bb, c_alpha, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
+        emit_grad(nt_c, acc, &mw, ba[0], p.gslot_trunk0 + (p.D - 2) * KH);
+      });
+    } else {
+      // ---- d h = fc_out^T d out, masked by relu'(layers_xyz[D-2] out) ----
+      BPiece cout{};
+      if (h == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if constexpr (BF16) cout[c] = static_cast<__bf16>(g[c]); else cout[c] = g[c];
+        }
+      }
+      uint4 mw = load_mask(p.D - 2);
+      auto c_out = [&](int, int) { return cout; };
+      run_stage<BF16, PT, NT, 0, 1, 0, false>(pipe, none, c_out, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
+        emit_grad(nt_c, acc, &mw, ba[0], p.gslot_trunk0 + (p.D - 2) * KH);
+      });
+    }
+    // ---- trunk, i = D-2 .. 0:  d x_i = layers_xyz[i][:, :W]^T d pre_i, masked by relu'(x_i) (x_0 = layer1 out: no mask)
+    //      `ba` holds d pre_i on entry.  Positions: both head variants leave the same offset mod 16 per precision/W.
+    constexpr int PV = ((NT / 2) + NT * (KH / 2) + NT * (KH + 1)) % kPhasePieces;  // viewdirs head
+    constexpr int PN = NT % kPhasePieces;                                            // fc_out head
+    auto trunk = [&](auto pos_c) {
+      constexpr int POS = decltype(pos_c)::value;
+      // mask words are fetched one stage ahead so the load is long complete at its first use
+      uint4 mw_nxt = (p.D - 3 >= 0) ? load_mask(p.D - 3) : make_uint4(0u, 0u, 0u, 0u);
+      for (int i = p.D - 2; i >= 0; --i) {
+        const uint4 mw = mw_nxt;
+        if (i - 2 >= 0) mw_nxt = load_mask(i - 2);
+        if (i > 0) {
+          run_stage<BF16, PT, NT, KH, 0, POS, false>(pipe, ba, no_pe, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
+            emit_grad(nt_c, acc, &mw, bb[0], p.gslot_trunk0 + (i - 1) * KH);
+          });
+        } else {
+          run_stage<BF16, PT, NT, KH, 0, POS, false>(pipe, ba, no_pe, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
+            emit_grad(nt_c, acc, nullptr, bb[0], p.gslot_layer1);
+          });
+        }
+#pragma unroll
+        for (int k = 0; k < KH; ++k) ba[0][k] = bb[0][k];
+      }
+      if constexpr (POS % kPhasePieces != 0) pipe.template skip<POS, kPhasePieces - POS>();
+    };
+    static_assert((NT * KH) % kPhasePieces == 0, "trunk stages must preserve the phase offset");
+    if (p.use_viewdirs) trunk(std::integral_constant<int, PV>{});
+    else trunk(std::integral_constant<int, PN>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+// ---- native piece layout -> plain (P, width) fp32 rows -------------------------------------------------------
+// kind 0: hidden vector (feature = 32*(q/PPT) + acc_row(...)); kind 1/2: xyz / dir positional encoding.
+template <bool BF16>
+__global__ void unpack_kernel(const char* __restrict__ native, int pieces_per_tile, int slot0, int n_pieces, int kind,
+                              int L, long long n_points, float* __restrict__ out, int ld_out, int col0) {
+  using P = Prec<BF16>;
+  const long long total = ((n_points + 31) / 32) * n_pieces * 64 * P::EPP;
+  for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+       idx += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int e = static_cast<int>(idx % P::EPP);
+    const int lane = static_cast<int>((idx / P::EPP) % 64);
+    const int q = static_cast<int>((idx / (P::EPP * 64)) % n_pieces);
+    const long long tile32 = idx / (static_cast<long long>(P::EPP) * 64 * n_pieces);
+    const int j = lane & 31, hh = lane >> 5;
+    const long long pt = tile32 * 32 + j;
+    if (pt >= n_points) continue;
+    int col;
+    if (kind == 0) col = (q / P::PPT) * 32 + acc_row((q % P::PPT) * P::EPP + e, hh);
+    else col = pe_slot_col(L, hh, q * P::EPP + e);
+    if (col < 0) continue;
+    const char* src = native + ((tile32 * pieces_per_tile + slot0 + q) * 64 + lane) * 16;
+    float v;
+    if constexpr (BF16) v = static_cast<float>(reinterpret_cast<const __bf16*>(src)[e]);
+    else v = reinterpret_cast<const float*>(src)[e];
+    out[pt * ld_out + col0 + col] = v;
+  }
+}
+
+template <int W, bool BF16>
+static int launch_backward(BwdParams p, hipStream_t stream) {
+  auto kern = mlp_backward_kernel<W, BF16>;
+  constexpr int WAVES = waves_of<BF16, 1>();
+  p.n_tiles = (p.n_points + WAVES * 32 - 1) / (WAVES * 32);
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -static_cast<int>(e); }
+    attr_set = true;
+  }
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  const long long grid = p.n_tiles < cus ? p.n_tiles : cus;
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(WAVES * 64), kRingBytes, stream, p);
+  return check_launch("mlp_backward");
+}
+
+static long long padded_tiles(long long n_points, int precision) {
+  // both training kernels process whole workgroup tiles; buffers are sized for the padded tile count
+  const int per_wg = 32 * (precision == DN_PREC_BF16 ? 8 : 4);
+  return (n_points + per_wg - 1) / per_wg * (per_wg / 32);
+}
+
+}  // namespace dn
+
+using namespace dn;
+
+extern "C" int dn_mlp_train_sizes(const dn_mlp_desc* desc, int precision, int64_t n_points, size_t* act_bytes,
+                                  size_t* mask_bytes, size_t* grad_bytes) {
+  int rc = validate_desc(desc, precision);
+  if (rc) return rc;
+  DN_REQUIRE(n_points >= 0 && act_bytes && mask_bytes && grad_bytes, "dn_mlp_train_sizes: bad arguments");
+  DN_REQUIRE(desc->num_encoding_fn_xyz == 10, "dn_mlp_train_sizes: training kernels are built for L_xyz = 10");
+  TrainLayout t;
+  build_train_layout(*desc, precision, &t);
+  const size_t tiles = static_cast<size_t>(padded_tiles(n_points, precision));
+  *act_bytes = tiles * t.act_pieces * kPieceBytes;
+  *mask_bytes = tiles * t.mask_words * kPieceBytes;
+  *grad_bytes = tiles * t.grad_pieces * kPieceBytes;
+  return 0;
+}
+
+extern "C" size_t dn_mlp_backward_packed_bytes(const dn_mlp_desc* desc, int precision) {
+  if (validate_desc(desc, precision)) return 0;
+  NetLayout L;
+  build_backward_layout(*desc, precision, &L);
+  return static_cast<size_t>(L.total_pieces) * kPieceBytes;
+}
+
+extern "C" int dn_mlp_pack_backward(const dn_mlp_desc* desc, int precision, const float* const* h_weights, void* packed,
+                                    dn_stream_t stream) {
+  int rc = validate_desc(desc, precision);
+  if (rc) return rc;
+  DN_REQUIRE(h_weights && packed, "dn_mlp_pack_backward: NULL pointer");
+  NetLayout L;
+  build_backward_layout(*desc, precision, &L);
+  const int n_params = desc->num_layers + (desc->use_viewdirs ? 4 : 1);
+  PackPtrs ptrs{};
+  for (int i = 0; i < n_params; ++i) {
+    DN_REQUIRE(h_weights[i], "dn_mlp_pack_backward: parameter %d is NULL", i);
+    ptrs.w[i] = h_weights[i];
+    ptrs.b[i] = h_weights[i];  // unused (no bias tiles in the backward stream)
+  }
+  return launch_pack(L, ptrs, packed, precision, as_stream(stream));
+}
+
+extern "C" int dn_run_network_train(const dn_mlp_desc* desc, int precision, const void* packed, const float* pts,
+                                    const float* viewdirs, const float* rays, int ray_stride, const float* z_vals,
+                                    int64_t n_rays, int samples_per_ray, float* out, void* act, void* masks,
+                                    dn_stream_t stream) {
+  FwdParams p;
+  int rc = setup_params(desc, precision, packed, &p);
+  if (rc) return rc;
+  DN_REQUIRE(packed && out && act && masks && n_rays >= 0 && samples_per_ray >= 1, "dn_run_network_train: bad arguments");
+  DN_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(masks)) & 15) == 0,
+             "dn_run_network_train: buffers must be 16-byte aligned");
+  if (pts != nullptr) {
+    DN_REQUIRE(!desc->use_viewdirs || viewdirs, "dn_run_network_train: viewdirs required with use_viewdirs");
+    p.mode = 1; p.pts = pts; p.viewdirs = viewdirs;
+  } else {
+    DN_REQUIRE(rays && z_vals, "dn_run_network_train: need pts, or rays + z_vals");
+    DN_REQUIRE(ray_stride >= (desc->use_viewdirs ? 11 : 8), "dn_run_network_train: ray_stride too small");
+    p.mode = 0; p.rays = rays; p.ray_stride = ray_stride; p.z = z_vals;
+  }
+  p.n_points = n_rays * samples_per_ray;
+  p.S = samples_per_ray;
+  p.out = out;
+  TrainLayout t;
+  build_train_layout(*desc, precision, &t);
+  p.act = static_cast<char*>(act);
+  p.masks = static_cast<char*>(masks);
+  p.act_pieces = t.act_pieces; p.mask_words = t.mask_words;
+  p.slot_xyz = t.slot_xyz; p.slot_dir = t.slot_dir; p.slot_layer1 = t.slot_layer1; p.slot_trunk0 = t.slot_trunk0;
+  p.slot_feat = t.slot_feat; p.slot_dirout = t.slot_dirout;
+  if (p.n_points == 0) return 0;
+  return dispatch_forward(*desc, precision, p, as_stream(stream));
+}
+
+extern "C" int dn_mlp_backward_data(const dn_mlp_desc* desc, int precision, const void* packed_bwd, const float* g_out,
+                                    const void* masks, int64_t n_points, void* grads, dn_stream_t stream) {
+  int rc = validate_desc(desc, precision);
+  if (rc) return rc;
+  DN_REQUIRE(packed_bwd && g_out && masks && grads && n_points >= 0, "dn_mlp_backward_data: bad arguments");
+  DN_REQUIRE((reinterpret_cast<uintptr_t>(g_out) & 15) == 0, "dn_mlp_backward_data: g_out must be 16-byte aligned");
+  if (n_points == 0) return 0;
+  NetLayout L;
+  build_backward_layout(*desc, precision, &L);
+  TrainLayout t;
+  build_train_layout(*desc, precision, &t);
+  BwdParams p{};
+  p.packed = static_cast<const char*>(packed_bwd);
+  p.total_pieces = L.total_pieces;
+  p.D = desc->num_layers;
+  p.use_viewdirs = desc->use_viewdirs;
+  p.g_out = g_out;
+  p.masks = static_cast<const char*>(masks);
+  p.mask_words = t.mask_words;
+  p.n_points = n_points;
+  p.grads = static_cast<char*>(grads);
+  p.grad_pieces = t.grad_pieces;
+  p.gslot_dirout = t.gslot_dirout; p.gslot_feat = t.gslot_feat; p.gslot_trunk0 = t.gslot_trunk0; p.gslot_layer1 = t.gslot_layer1;
+  const bool bf = precision == DN_PREC_BF16;
+  if (desc->hidden_size == 256) return bf ? launch_backward<256, true>(p, as_stream(stream)) : launch_backward<256, false>(p, as_stream(stream));
+  if (desc->hidden_size == 128) return bf ? launch_backward<128, true>(p, as_stream(stream)) : launch_backward<128, false>(p, as_stream(stream));
+  set_error("dn_mlp_backward_data: no kernel instance for W=%d", desc->hidden_size);
+  return DN_E_UNSUPPORTED;
+}
+
+extern "C" int dn_mlp_unpack(const dn_mlp_desc* desc, int precision, int which, const void* native, int64_t n_points,
+                             int slot, int width, int kind, float* out, int ld_out, int col0, dn_stream_t stream) {
+  int rc = validate_desc(desc, precision);
+  if (rc) return rc;
+  DN_REQUIRE(native && out && n_points >= 0 && width > 0 && ld_out >= col0 + 1 && (which == 0 || which == 1) && kind >= 0 && kind <= 2,
+             "dn_mlp_unpack: bad arguments");
+  if (n_points == 0) return 0;
+  TrainLayout t;
+  build_train_layout(*desc, precision, &t);
+  const int per_tile = which == 0 ? t.act_pieces : t.grad_pieces;
+  const int n_pieces = (kind == 0) ? width / t.kpp : (kind == 1 ? t.kxp : t.kdp);
+  const int L = kind == 1 ? desc->num_encoding_fn_xyz : desc->num_encoding_fn_dir;
+  DN_REQUIRE(slot >= 0 && slot + n_pieces <= per_tile, "dn_mlp_unpack: slot range outside the tile");
+  if (precision == DN_PREC_BF16)
+    hipLaunchKernelGGL(unpack_kernel<true>, dim3(2048), dim3(256), 0, as_stream(stream), static_cast<const char*>(native),
+                       per_tile, slot, n_pieces, kind, L, n_points, out, ld_out, col0);
+  else
+    hipLaunchKernelGGL(unpack_kernel<false>, dim3(2048), dim3(256), 0, as_stream(stream), static_cast<const char*>(native),
+                       per_tile, slot, n_pieces, kind, L, n_points, out, ld_out, col0);
+  return check_launch("dn_mlp_unpack");
+}

@@ -20,6 +20,8 @@ EXPORTS = (
     "dn_abi_version", "dn_last_error", "dn_ray_bundle", "dn_coarse_depths", "dn_positional_encoding",
     "dn_mlp_packed_bytes", "dn_mlp_pack", "dn_run_network", "dn_mlp_forward_encoded", "dn_volume_render",
     "dn_volume_render_backward", "dn_sample_pdf", "dn_fine_depths", "dn_render_workspace_bytes", "dn_render_rays",
+    "dn_mlp_train_sizes", "dn_mlp_backward_packed_bytes", "dn_mlp_pack_backward", "dn_run_network_train",
+    "dn_mlp_backward_data", "dn_mlp_unpack",
 )
 
 
@@ -56,8 +58,17 @@ def _declare(lib):
     lib.dn_render_rays.argtypes = [POINTER(MlpDesc), vp, POINTER(MlpDesc), vp, c_int, fp, c_int, c_int64, c_int, c_int,
                                    c_int, c_float, c_int, POINTER(c_float), c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp,
                                    fp, fp, vp, vp]
+    lib.dn_mlp_train_sizes.argtypes = [POINTER(MlpDesc), c_int, c_int64, POINTER(c_size_t), POINTER(c_size_t),
+                                       POINTER(c_size_t)]
+    lib.dn_mlp_backward_packed_bytes.argtypes = [POINTER(MlpDesc), c_int]
+    lib.dn_mlp_backward_packed_bytes.restype = c_size_t
+    lib.dn_mlp_pack_backward.argtypes = [POINTER(MlpDesc), c_int, POINTER(c_void_p), vp, vp]
+    lib.dn_run_network_train.argtypes = [POINTER(MlpDesc), c_int, vp, fp, fp, fp, c_int, fp, c_int64, c_int, fp, vp, vp, vp]
+    lib.dn_mlp_backward_data.argtypes = [POINTER(MlpDesc), c_int, vp, fp, vp, c_int64, vp, vp]
+    lib.dn_mlp_unpack.argtypes = [POINTER(MlpDesc), c_int, c_int, vp, c_int64, c_int, c_int, c_int, fp, c_int, c_int, vp]
     for name in EXPORTS:
-        if name not in ("dn_last_error", "dn_mlp_packed_bytes", "dn_render_workspace_bytes"):
+        if name not in ("dn_last_error", "dn_mlp_packed_bytes", "dn_render_workspace_bytes",
+                        "dn_mlp_backward_packed_bytes"):
             getattr(lib, name).restype = c_int
 
 

@@ -72,6 +72,8 @@ class PackedMLP:
             check(-1001, "dn_mlp_packed_bytes")
         self.buffer = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.key = None
+        self.buffer_bwd = None   # transposed stream for the backward-data chain, packed on first training use
+        self.key_bwd = None
 
     def pack(self, weights, biases):
         """weights/biases: lists of device tensors in the reference parameter order."""
@@ -82,6 +84,58 @@ class PackedMLP:
         bp = (c_void_p * n)(*[b.data_ptr() for b in bs])
         check(lib().dn_mlp_pack(ctypes.byref(self.desc), self.precision, wp, bp, ptr(self.buffer), stream()), "dn_mlp_pack")
         self._keep = (ws, bs)  # keep sources alive until the pack kernel has run on this stream
+
+
+def pack_backward(packed, weights):
+    """(Re)build the transposed weight stream used by dn_mlp_backward_data."""
+    if packed.buffer_bwd is None:
+        nbytes = lib().dn_mlp_backward_packed_bytes(ctypes.byref(packed.desc), packed.precision)
+        packed.buffer_bwd = torch.empty(nbytes, dtype=torch.uint8, device=packed.buffer.device)
+    ws = [f32c(w.detach()) for w in weights]
+    wp = (c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+    check(lib().dn_mlp_pack_backward(ctypes.byref(packed.desc), packed.precision, wp, ptr(packed.buffer_bwd), stream()),
+          "dn_mlp_pack_backward")
+    packed._keep_bwd = ws
+
+
+def train_sizes(packed, n_points):
+    a, m, g = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    check(lib().dn_mlp_train_sizes(ctypes.byref(packed.desc), packed.precision, n_points, ctypes.byref(a), ctypes.byref(m),
+                                   ctypes.byref(g)), "dn_mlp_train_sizes")
+    return a.value, m.value, g.value
+
+
+def run_network_train(packed, pts, viewdirs, samples_per_ray):
+    """Training forward: raw radiance field + the opaque (act, masks) buffers the backward needs."""
+    pts = f32c(pts).reshape(-1, 3)
+    n_pts = pts.shape[0]
+    assert n_pts % samples_per_ray == 0
+    dev = pts.device
+    a_bytes, m_bytes, _ = train_sizes(packed, n_pts)
+    out = torch.empty((n_pts, 4), dtype=torch.float32, device=dev)
+    act = torch.empty(a_bytes, dtype=torch.uint8, device=dev)
+    masks = torch.empty(m_bytes, dtype=torch.uint8, device=dev)
+    vd = None if viewdirs is None else f32c(viewdirs).reshape(-1, 3)
+    check(lib().dn_run_network_train(ctypes.byref(packed.desc), packed.precision, ptr(packed.buffer), ptr(pts), ptr(vd), None,
+                                     0, None, n_pts // samples_per_ray, samples_per_ray, ptr(out), ptr(act), ptr(masks),
+                                     stream()), "dn_run_network_train")
+    return out, act, masks
+
+
+def mlp_backward_data(packed, g_out, masks, n_points):
+    g_out = f32c(g_out).reshape(-1, 4)
+    _, _, g_bytes = train_sizes(packed, n_points)
+    grads = torch.empty(g_bytes, dtype=torch.uint8, device=g_out.device)
+    check(lib().dn_mlp_backward_data(ctypes.byref(packed.desc), packed.precision, ptr(packed.buffer_bwd), ptr(g_out),
+                                     ptr(masks), n_points, ptr(grads), stream()), "dn_mlp_backward_data")
+    return grads
+
+
+def mlp_unpack(packed, which, native, n_points, slot, width, kind, out, col0=0):
+    """native pieces -> out[:, col0:col0+width_or_pe_dim] (plain fp32 rows)."""
+    check(lib().dn_mlp_unpack(ctypes.byref(packed.desc), packed.precision, which, ptr(native), n_points, slot, width, kind,
+                              ptr(out), out.shape[1], col0, stream()), "dn_mlp_unpack")
+    return out
 
 
 def run_network_pts(packed, pts, viewdirs, samples_per_ray):

@@ -1,18 +1,106 @@
-"""Dispatch between the fused HIP network kernel (inference) and the autograd path (training).
+"""Dispatch between the fused HIP network kernels and PyTorch autograd.
 
-Round-1 state: the fused kernel is forward-only.  When gradients w.r.t. the parameters are needed the
-network is evaluated as the same nn.Linear composition on the device (rocBLAS GEMMs, differentiated by
-PyTorch), fed by the HIP positional-encoding kernel and followed by the HIP compositing forward/backward
-(`_ops.VolumeRenderFn`).  A fused backward chain is the planned replacement ("next")."""
+Inference: one fused kernel (positional encoding + MLP).  Training, for the nets the training kernels cover
+(W in {128, 256}, L_xyz = 10): `FusedNetFn` - a fused forward that keeps every stage's output and ReLU masks in a
+wave-native layout, and a fused backward-data chain on the transposed weight stream (dn_mlp_backward_data);
+the weight/bias gradients are then dY^T X GEMMs (library GEMM) over the unpacked rows.  Other configurations
+differentiate the nn.Linear composition directly."""
 import torch
 
-from . import _ops
+from . import _hip, _ops
 
 
 def needs_grad(model, *tensors):
     if not torch.is_grad_enabled():
         return False
     return any(t is not None and t.requires_grad for t in tensors) or any(p.requires_grad for p in model.parameters())
+
+
+def train_fused_ok(model):
+    return model.fused_ok() and model.num_encoding_fn_xyz == 10
+
+
+def _slots(model, precision):
+    """Piece slots of the saved activations / gradients (mirrors TrainLayout in csrc/mlp_layout.h)."""
+    kpp = 16 if precision == _hip.PREC_BF16 else 8
+    w, d = model.hidden_size, model.num_layers
+    kxp = ((model.dim_xyz + 15) // 16 * 16) // kpp
+    kdp = (((model.dim_dir + 15) // 16 * 16) // kpp) if model.use_viewdirs else 0
+    kh = w // kpp
+    s = {"xyz": 0, "dir": kxp, "layer1": kxp + kdp}
+    s["trunk0"] = s["layer1"] + kh
+    s["feat"] = s["trunk0"] + (d - 1) * kh
+    s["dirout"] = s["feat"] + (kh if model.use_viewdirs else 0)
+    g = {"dirout": 0}
+    g["feat"] = (kh // 2) if model.use_viewdirs else 0
+    g["trunk0"] = g["feat"] + (kh if model.use_viewdirs else 0)
+    g["layer1"] = g["trunk0"] + (d - 1) * kh
+    return s, g, kh
+
+
+class FusedNetFn(torch.autograd.Function):
+    """run_network for a FlexibleNeRFModel, differentiable w.r.t. the model parameters (points carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, model, pts, viewdirs, samples_per_ray, log_xyz, log_dir, *params):
+        pk = model.packed(log_xyz, log_dir)
+        mods = model.linear_modules()
+        key = tuple((m.weight.data_ptr(), m.weight._version) for m in mods)
+        if pk.key_bwd != key:
+            _ops.pack_backward(pk, [m.weight for m in mods])
+            pk.key_bwd = key
+        out, act, masks = _ops.run_network_train(pk, pts, viewdirs, samples_per_ray)
+        ctx.model, ctx.pk = model, pk
+        ctx.n_points = out.shape[0]
+        ctx.save_for_backward(act, masks)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        model, pk, n = ctx.model, ctx.pk, ctx.n_points
+        act, masks = ctx.saved_tensors
+        g_out = g_out.contiguous().float()
+        grads = _ops.mlp_backward_data(pk, g_out, masks, n)
+        slots, gslots, kh = _slots(model, pk.precision)
+        w, d, dev = model.hidden_size, model.num_layers, g_out.device
+
+        def rows(width):
+            return torch.empty((n, width), dtype=torch.float32, device=dev)
+
+        def act_hidden(slot, width, out=None, col0=0):
+            out = rows(width) if out is None else out
+            return _ops.mlp_unpack(pk, 0, act, n, slot, width, 0, out, col0)
+
+        def grad_hidden(slot, width):
+            return _ops.mlp_unpack(pk, 1, grads, n, slot, width, 0, rows(width))
+
+        results = {}
+
+        def put(mod, dy, x):
+            results[mod] = (dy.t() @ x, dy.sum(0))
+
+        pe_xyz = _ops.mlp_unpack(pk, 0, act, n, slots["xyz"], model.dim_xyz, 1, rows(model.dim_xyz))
+        put(model.layer1, grad_hidden(gslots["layer1"], w), pe_xyz)
+        x_prev = act_hidden(slots["layer1"], w)
+        for i, layer in enumerate(model.layers_xyz):
+            dy = grad_hidden(gslots["trunk0"] + i * kh, w)
+            x = torch.cat((x_prev, pe_xyz), dim=-1) if i in model.skip_layers else x_prev
+            put(layer, dy, x)
+            x_prev = act_hidden(slots["trunk0"] + i * kh, w)
+        if model.use_viewdirs:
+            put(model.fc_feat, grad_hidden(gslots["feat"], w), x_prev)
+            put(model.fc_alpha, g_out[:, 3:4], x_prev)
+            x_dir = rows(w + model.dim_dir)
+            act_hidden(slots["feat"], w, x_dir, 0)
+            _ops.mlp_unpack(pk, 0, act, n, slots["dir"], model.dim_dir, 2, x_dir, w)
+            put(model.layers_dir[0], grad_hidden(gslots["dirout"], w // 2), x_dir)
+            put(model.fc_rgb, g_out[:, :3], act_hidden(slots["dirout"], w // 2))
+        else:
+            put(model.fc_out, g_out, x_prev)
+        flat = []
+        for m in model.linear_modules():
+            flat.extend(results[m])
+        return (None, None, None, None, None, None) + tuple(flat)
 
 
 def mlp_encoded(model, x):
@@ -23,5 +111,10 @@ def mlp_encoded(model, x):
 
 
 def run_network_fused(model, pts, viewdirs, samples_per_ray, log_xyz=True, log_dir=True):
-    """run_network on raw points: positional encoding + MLP in one kernel (no autograd)."""
+    """run_network on raw points: positional encoding + MLP in one kernel; differentiable w.r.t. the parameters."""
+    if needs_grad(model) and train_fused_ok(model):
+        params = []
+        for m in model.linear_modules():
+            params += [m.weight, m.bias]
+        return FusedNetFn.apply(model, pts, viewdirs, samples_per_ray, log_xyz, log_dir, *params)
     return _ops.run_network_pts(model.packed(log_xyz, log_dir), pts, viewdirs, samples_per_ray)

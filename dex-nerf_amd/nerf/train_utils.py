@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from . import _ops
-from ._train import needs_grad, run_network_fused
+from ._train import needs_grad, run_network_fused, train_fused_ok
 from .models import FlexibleNeRFModel
 from .nerf_helpers import Embedder, _require_device, get_minibatches, ndc_rays
 from .nerf_helpers import sample_pdf_2 as sample_pdf  # noqa: F401  (reference train_utils.py:6 alias)
@@ -78,7 +78,7 @@ def run_network(network_fn, pts, ray_batch, chunksize, embed_fn, embeddirs_fn):
     HIP kernel (encoding never materialised); any other callable gets the generic composition:
     HIP encoding -> network_fn minibatches -> concat."""
     _require_device(pts, "run_network")
-    if _fusable(network_fn, embed_fn, embeddirs_fn) and not needs_grad(network_fn, pts):
+    if _fusable(network_fn, embed_fn, embeddirs_fn) and (train_fused_ok(network_fn) or not needs_grad(network_fn, pts)):
         s = pts.shape[-2] if pts.dim() >= 2 else 1
         viewdirs = ray_batch[..., -3:] if network_fn.use_viewdirs else None
         log_dir = embeddirs_fn.log_sampling if network_fn.use_viewdirs else True

@@ -352,3 +352,192 @@ extern "C" int dn_mlp_unpack(const dn_mlp_desc* desc, int precision, int which, 
                        per_tile, slot, n_pieces, kind, L, n_points, out, ld_out, col0);
   return check_launch("dn_mlp_unpack");
 }
+
+// ==============================================================================================================
+// Weight / bias gradients straight from the wave-native buffers (bf16):  dW[n][k] += sum_p dY[p][n] X[p][k].
+// The contraction runs over POINTS, which both saved tensors keep on the lane axis, so each 1 KiB native piece
+// (64 lanes x 8 features) is staged in LDS as is (LDS-DMA, lane-linear) and read back TRANSPOSED with
+// ds_read_b64_tr_b16: a 16-lane group fetches 4 points x 16 features and every lane receives one feature of those
+// 4 points - two reads build the 8-point MFMA fragment of one feature row.  One workgroup owns the whole
+// (N x K) gradient of a layer for a strided set of 32-point tiles (8 waves: one 32-row n-tile each, all k-tiles)
+// and adds its partial with fp32 atomics at the end (128-byte row segments).  An all-ones B tile yields db.
+// HBM-bound: (N + K) x 2 B per point against 2 N K FLOP per point (146 FLOP/B at 256 x 320).
+// ==============================================================================================================
+namespace dn {
+
+constexpr int kWgMaxKTiles = 11;  // 8 hidden + 2 xyz-PE + 1 all-ones (bias) tile
+
+struct WgParams {
+  const char* act;
+  const char* grads;
+  int act_pieces, grad_pieces;
+  long long n_points;
+  int g_slot, n_tiles_n;          // dY pieces: g_slot .. g_slot + 2*n_tiles_n
+  int x_slot, x_tiles;            // hidden X pieces (2 per 32-feature tile), may be 0
+  int pe_slot, pe_tiles, pe_L;    // positional-encoding pieces appended to X
+  float* dW;
+  int ldw, col_pe0;
+  float* db;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* piece_lane /* piece base + this lane's transposing offset */,
+                                          int point0 /* first of the 8 points, multiple of 4 */) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(piece_lane + point0 * 16));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(piece_lane + (point0 + 4) * 16));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// feature index (within a 32-feature tile) that transposed fragment row/column `i` (0..31) refers to
+__device__ __forceinline__ int tr_feature(int i) {
+  const int fs = i >> 4, li = i & 15;
+  return acc_row(fs * 8 + (li & 7), li >> 3);
+}
+
+__global__ __launch_bounds__(512, 2) void weight_grad_kernel(WgParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_dy = 2 * p.n_tiles_n, n_x = 2 * p.x_tiles, n_pe = 2 * p.pe_tiles;
+  const int n_pieces = n_dy + n_x + n_pe;
+  const int buf_bytes = n_pieces * kPieceBytes;
+  const long long tiles = (p.n_points + 31) / 32;
+
+  // wave -> (n-tile, subset of k-tiles)
+  const int ntile = wave % p.n_tiles_n;
+  const int kgroup = wave / p.n_tiles_n;
+  const int kgroups = 8 / p.n_tiles_n;
+  const int kt_total = p.x_tiles + p.pe_tiles + 1;  // + all-ones tile
+
+  // transposing read: lane (16-lane group g, li) supplies row (li>>2) / column chunk (li&3) of a 4 x 16 block and
+  // receives feature column li; group g covers feature sub-block fs = g&1 and k-half hh = g>>1 of the MFMA operand
+  const int li = lane & 15, grp = lane >> 4;
+  const int fs = grp & 1, hh = grp >> 1;
+  const int lane_off = ((((li & 3) >> 1) * 32 + (li >> 2) + 8 * hh) * 16) + ((li & 3) & 1) * 8;
+
+  auto stage = [&](long long tile32, int buf) {
+    char* dst = smem + buf * buf_bytes;
+    for (int pi = wave; pi < n_pieces; pi += 8) {
+      const char* src;
+      if (pi < n_dy) src = p.grads + ((tile32 * p.grad_pieces + p.g_slot + pi) * 64 + lane) * 16;
+      else if (pi < n_dy + n_x) src = p.act + ((tile32 * p.act_pieces + p.x_slot + (pi - n_dy)) * 64 + lane) * 16;
+      else src = p.act + ((tile32 * p.act_pieces + p.pe_slot + (pi - n_dy - n_x)) * 64 + lane) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + pi * kPieceBytes), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[kWgMaxKTiles];
+#pragma unroll
+  for (int k = 0; k < kWgMaxKTiles; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = static_cast<__bf16>(1.0f);
+
+  long long tile = blockIdx.x;
+  int buf = 0;
+  if (tile < tiles) stage(tile, 0);
+  for (; tile < tiles; tile += gridDim.x) {
+    __syncthreads();  // (hipcc drains the LDS-DMA with vmcnt(0) first) this tile landed; previous tile fully consumed
+    const long long nxt = tile + gridDim.x;
+    if (nxt < tiles) stage(nxt, buf ^ 1);
+    const char* base = smem + buf * buf_bytes + lane_off;
+    // A = dY^T fragments of this wave's n-tile, two 16-point k-steps
+    bf16x8 a0 = tr_frag(base + (2 * ntile + fs) * kPieceBytes, 0);
+    bf16x8 a1 = tr_frag(base + (2 * ntile + fs) * kPieceBytes, 16);
+    const long long valid = p.n_points - tile * 32;  // points of this tile that exist (the rest are padding copies)
+    if (valid < 32) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (8 * hh + e >= valid) a0[e] = static_cast<__bf16>(0.0f);
+        if (16 + 8 * hh + e >= valid) a1[e] = static_cast<__bf16>(0.0f);
+      }
+    }
+    static_for<kWgMaxKTiles>([&](auto kt_c) {
+      constexpr int kt = decltype(kt_c)::value;
+      if (kt < kt_total && (kt % kgroups) == kgroup) {
+        bf16x8 b0 = ones, b1 = ones;
+        if (kt < kt_total - 1) {
+          const char* pb = base + (n_dy + 2 * kt + fs) * kPieceBytes;
+          b0 = tr_frag(pb, 0);
+          b1 = tr_frag(pb, 16);
+        }
+        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[kt], 0, 0, 0);
+      }
+    });
+    buf ^= 1;
+  }
+  // ---- add this workgroup's partial: D[i][j] sits in lane (j = lane&31, half = lane>>5), register r, i = acc_row(r, half)
+  const int j = lane & 31, half = lane >> 5;
+  static_for<kWgMaxKTiles>([&](auto kt_c) {
+    constexpr int kt = decltype(kt_c)::value;
+    if (kt < kt_total && (kt % kgroups) == kgroup) {
+      int col;
+      if (kt < p.x_tiles) col = 32 * kt + tr_feature(j);
+      else if (kt < kt_total - 1) {
+        const int pe_piece = 2 * (kt - p.x_tiles) + (j >> 4);
+        const int pc = pe_slot_col(p.pe_L, (j & 15) >> 3, pe_piece * 8 + (j & 7));
+        col = pc >= 0 ? p.col_pe0 + pc : -1;
+      } else col = (j == 0) ? -2 : -1;  // all-ones tile: column 0 carries the bias gradient
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = 32 * ntile + tr_feature(acc_row(r, half));
+        if (col >= 0) atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col, acc[kt][r]);
+        else if (col == -2 && p.db != nullptr) atomicAdd(p.db + n, acc[kt][r]);
+      }
+    }
+  });
+}
+
+}  // namespace dn
+
+extern "C" int dn_mlp_weight_grad(const dn_mlp_desc* desc, int precision, const void* act, const void* grads,
+                                  int64_t n_points, int g_slot, int n_out, int x_slot, int x_width, int pe_kind,
+                                  float* dW, int ldw, float* db, dn_stream_t stream) {
+  int rc = validate_desc(desc, precision);
+  if (rc) return rc;
+  DN_REQUIRE(precision == DN_PREC_BF16, "dn_mlp_weight_grad: bf16 buffers only (fp32 mode forms dW with library GEMMs)");
+  DN_REQUIRE(act && grads && dW && n_points >= 0 && n_out % 32 == 0 && x_width % 32 == 0 && pe_kind >= 0 && pe_kind <= 2,
+             "dn_mlp_weight_grad: bad arguments");
+  if (n_points == 0) return 0;
+  TrainLayout t;
+  build_train_layout(*desc, precision, &t);
+  WgParams p{};
+  p.act = static_cast<const char*>(act);
+  p.grads = static_cast<const char*>(grads);
+  p.act_pieces = t.act_pieces; p.grad_pieces = t.grad_pieces;
+  p.n_points = n_points;
+  p.g_slot = g_slot; p.n_tiles_n = n_out / 32;
+  p.x_slot = x_slot; p.x_tiles = x_width / 32;
+  p.pe_slot = pe_kind == 1 ? t.slot_xyz : t.slot_dir;
+  p.pe_tiles = pe_kind == 0 ? 0 : (pe_kind == 1 ? t.kxp : t.kdp) / 2;
+  p.pe_L = pe_kind == 1 ? desc->num_encoding_fn_xyz : desc->num_encoding_fn_dir;
+  p.dW = dW; p.ldw = ldw; p.col_pe0 = x_width; p.db = db;
+  DN_REQUIRE(p.n_tiles_n == 8 || p.n_tiles_n == 4 || p.n_tiles_n == 2, "dn_mlp_weight_grad: n_out must be 256, 128 or 64");
+  DN_REQUIRE(p.x_tiles + p.pe_tiles + 1 <= kWgMaxKTiles * (8 / p.n_tiles_n), "dn_mlp_weight_grad: too many input columns");
+  const int n_pieces = 2 * (p.n_tiles_n + p.x_tiles + p.pe_tiles);
+  const size_t lds = static_cast<size_t>(2) * n_pieces * kPieceBytes;
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(weight_grad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -static_cast<int>(e); }
+    attr_set = true;
+  }
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  const long long tiles = (n_points + 31) / 32;
+  const long long grid = tiles < 2 * cus ? tiles : 2 * cus;
+  hipLaunchKernelGGL(weight_grad_kernel, dim3(static_cast<unsigned>(grid)), dim3(512), lds, as_stream(stream), p);
+  return check_launch("dn_mlp_weight_grad");
+}

@@ -138,6 +138,12 @@ def mlp_unpack(packed, which, native, n_points, slot, width, kind, out, col0=0):
     return out
 
 
+def mlp_weight_grad(packed, act, grads, n_points, g_slot, n_out, x_slot, x_width, pe_kind, d_w, d_b):
+    """bf16 buffers: d_w (n_out, >= x_width + pe_dim) += dY^T [X | PE], d_b += sum dY (both pre-zeroed fp32)."""
+    check(lib().dn_mlp_weight_grad(ctypes.byref(packed.desc), packed.precision, ptr(act), ptr(grads), n_points, g_slot, n_out,
+                                   x_slot, x_width, pe_kind, ptr(d_w), d_w.shape[1], ptr(d_b), stream()), "dn_mlp_weight_grad")
+
+
 def run_network_pts(packed, pts, viewdirs, samples_per_ray):
     pts = f32c(pts).reshape(-1, 3)
     n_pts = pts.shape[0]

@@ -79,6 +79,31 @@ class FusedNetFn(torch.autograd.Function):
         def put(mod, dy, x):
             results[mod] = (dy.t() @ x, dy.sum(0))
 
+        if pk.precision == _hip.PREC_BF16:
+            # weight/bias gradients of the wide layers straight from the native buffers (MFMA kernel, fp32 atomics)
+            def native(mod, g_slot, n_out, x_slot, x_width, pe_kind):
+                d_w = torch.zeros_like(mod.weight, dtype=torch.float32)
+                d_b = torch.zeros_like(mod.bias, dtype=torch.float32)
+                _ops.mlp_weight_grad(pk, act, grads, n, g_slot, n_out, x_slot, x_width, pe_kind, d_w, d_b)
+                results[mod] = (d_w, d_b)
+
+            native(model.layer1, gslots["layer1"], w, 0, 0, 1)
+            x_slot = slots["layer1"]
+            for i, layer in enumerate(model.layers_xyz):
+                native(layer, gslots["trunk0"] + i * kh, w, x_slot, w, 1 if i in model.skip_layers else 0)
+                x_slot = slots["trunk0"] + i * kh
+            if model.use_viewdirs:
+                native(model.fc_feat, gslots["feat"], w, x_slot, w, 0)
+                put(model.fc_alpha, g_out[:, 3:4], act_hidden(x_slot, w))
+                native(model.layers_dir[0], gslots["dirout"], w // 2, slots["feat"], w, 2)
+                put(model.fc_rgb, g_out[:, :3], act_hidden(slots["dirout"], w // 2))
+            else:
+                put(model.fc_out, g_out, act_hidden(x_slot, w))
+            flat = []
+            for m in model.linear_modules():
+                flat.extend(results[m])
+            return (None, None, None, None, None, None) + tuple(flat)
+
         pe_xyz = _ops.mlp_unpack(pk, 0, act, n, slots["xyz"], model.dim_xyz, 1, rows(model.dim_xyz))
         put(model.layer1, grad_hidden(gslots["layer1"], w), pe_xyz)
         x_prev = act_hidden(slots["layer1"], w)

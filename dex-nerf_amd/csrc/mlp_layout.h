@@ -124,6 +124,7 @@ struct TrainLayout {
   int32_t mask_words;               // 16-byte mask words per lane per tile: (D-1) trunk + feat + dirout
   int32_t grad_pieces;              // saved dL/d(pre-activation) pieces per tile
   int32_t gslot_dirout, gslot_feat, gslot_trunk0, gslot_layer1;  // gslot_trunk0 + i*kh for layers_xyz[i]
+  int32_t gslot_out;  // the output gradient as "custom" pieces: [d rgb | d alpha] (viewdirs) or [d out]
 };
 
 inline void build_train_layout(const dn_mlp_desc& d, int precision, TrainLayout* t) {
@@ -147,6 +148,7 @@ inline void build_train_layout(const dn_mlp_desc& d, int precision, TrainLayout*
   t->gslot_feat = g; g += d.use_viewdirs ? t->kh : 0;
   t->gslot_trunk0 = g; g += (D - 1) * t->kh;
   t->gslot_layer1 = g; g += t->kh;
+  t->gslot_out = g; g += d.use_viewdirs ? 2 : 1;
   t->grad_pieces = g;
 }
 

@@ -24,7 +24,7 @@ struct BwdParams {
   long long n_tiles;
   char* grads;             // [tile32][grad_pieces][64][16 B]
   int grad_pieces;
-  int gslot_dirout, gslot_feat, gslot_trunk0, gslot_layer1;
+  int gslot_dirout, gslot_feat, gslot_trunk0, gslot_layer1, gslot_out;
 };
 
 template <int W, bool BF16>
@@ -106,6 +106,8 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
           calpha[0] = g[3];
         }
       }
+      *reinterpret_cast<BPiece*>(grad_base + static_cast<long long>(p.gslot_out) * 1024) = crgb;      // for dW(fc_rgb)
+      *reinterpret_cast<BPiece*>(grad_base + static_cast<long long>(p.gslot_out + 1) * 1024) = calpha;  // for dW(fc_alpha)
       // ---- d g = fc_rgb^T d rgb, masked by relu'(layers_dir.0 out) ----
       uint4 mw = load_mask(p.D);
       uint4 mw_next = load_mask(p.D - 1);
@@ -136,6 +138,7 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
           if constexpr (BF16) cout[c] = static_cast<__bf16>(g[c]); else cout[c] = g[c];
         }
       }
+      *reinterpret_cast<BPiece*>(grad_base + static_cast<long long>(p.gslot_out) * 1024) = cout;  // for dW(fc_out)
       uint4 mw = load_mask(p.D - 2);
       auto c_out = [&](int, int) { return cout; };
       run_stage<BF16, PT, NT, 0, 1, 0, false>(pipe, none, c_out, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
@@ -324,6 +327,7 @@ extern "C" int dn_mlp_backward_data(const dn_mlp_desc* desc, int precision, cons
   p.grads = static_cast<char*>(grads);
   p.grad_pieces = t.grad_pieces;
   p.gslot_dirout = t.gslot_dirout; p.gslot_feat = t.gslot_feat; p.gslot_trunk0 = t.gslot_trunk0; p.gslot_layer1 = t.gslot_layer1;
+  p.gslot_out = t.gslot_out;
   const bool bf = precision == DN_PREC_BF16;
   if (desc->hidden_size == 256) return bf ? launch_backward<256, true>(p, as_stream(stream)) : launch_backward<256, false>(p, as_stream(stream));
   if (desc->hidden_size == 128) return bf ? launch_backward<128, true>(p, as_stream(stream)) : launch_backward<128, false>(p, as_stream(stream));
@@ -373,6 +377,7 @@ struct WgParams {
   int act_pieces, grad_pieces;
   long long n_points;
   int g_slot, n_tiles_n;          // dY pieces: g_slot .. g_slot + 2*n_tiles_n
+  int custom_rows;                // > 0: dY is ONE custom piece (element (half h, e) = output row 8h+e), rows < custom_rows real
   int x_slot, x_tiles;            // hidden X pieces (2 per 32-feature tile), may be 0
   int pe_slot, pe_tiles, pe_L;    // positional-encoding pieces appended to X
   float* dW;
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void weight_grad_kernel(WgParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n_dy = 2 * p.n_tiles_n, n_x = 2 * p.x_tiles, n_pe = 2 * p.pe_tiles;
+  const int n_dy = p.custom_rows > 0 ? 1 : 2 * p.n_tiles_n, n_x = 2 * p.x_tiles, n_pe = 2 * p.pe_tiles;
   const int n_pieces = n_dy + n_x + n_pe;
   const int buf_bytes = n_pieces * kPieceBytes;
   const long long tiles = (p.n_points + 31) / 32;
@@ -452,8 +457,14 @@ __global__ __launch_bounds__(512, 2) void weight_grad_kernel(WgParams p) {
     if (nxt < tiles) stage(nxt, buf ^ 1);
     const char* base = smem + buf * buf_bytes + lane_off;
     // A = dY^T fragments of this wave's n-tile, two 16-point k-steps
-    bf16x8 a0 = tr_frag(base + (2 * ntile + fs) * kPieceBytes, 0);
-    bf16x8 a1 = tr_frag(base + (2 * ntile + fs) * kPieceBytes, 16);
+    // (a custom dY has a single piece: the fs=1 lane groups re-read it and are zeroed below)
+    const int dy_piece = p.custom_rows > 0 ? 0 : 2 * ntile + fs;
+    bf16x8 a0 = tr_frag(base + dy_piece * kPieceBytes, 0);
+    bf16x8 a1 = tr_frag(base + dy_piece * kPieceBytes, 16);
+    if (p.custom_rows > 0 && fs == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a0[e] = static_cast<__bf16>(0.0f); a1[e] = static_cast<__bf16>(0.0f); }
+    }
     const long long valid = p.n_points - tile * 32;  // points of this tile that exist (the rest are padding copies)
     if (valid < 32) {
 #pragma unroll
@@ -491,7 +502,12 @@ __global__ __launch_bounds__(512, 2) void weight_grad_kernel(WgParams p) {
       } else col = (j == 0) ? -2 : -1;  // all-ones tile: column 0 carries the bias gradient
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = 32 * ntile + tr_feature(acc_row(r, half));
+        const int irow = acc_row(r, half);
+        int n = 32 * ntile + tr_feature(irow);
+        if (p.custom_rows > 0) {
+          n = (irow < 16) ? ((irow & 15) >> 3) * 8 + (irow & 7) : p.custom_rows;  // custom piece: row = 8h + e
+          if (n >= p.custom_rows) continue;
+        }
         if (col >= 0) atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col, acc[kt][r]);
         else if (col == -2 && p.db != nullptr) atomicAdd(p.db + n, acc[kt][r]);
       }
@@ -504,6 +520,8 @@ __global__ __launch_bounds__(512, 2) void weight_grad_kernel(WgParams p) {
 extern "C" int dn_mlp_weight_grad(const dn_mlp_desc* desc, int precision, const void* act, const void* grads,
                                   int64_t n_points, int g_slot, int n_out, int x_slot, int x_width, int pe_kind,
                                   float* dW, int ldw, float* db, dn_stream_t stream) {
+  const int custom_rows = (n_out < 32) ? n_out : 0;  // fc_rgb (3) / fc_alpha (1) / fc_out (4): one custom dY piece
+  if (custom_rows) n_out = 32;
   int rc = validate_desc(desc, precision);
   if (rc) return rc;
   DN_REQUIRE(precision == DN_PREC_BF16, "dn_mlp_weight_grad: bf16 buffers only (fp32 mode forms dW with library GEMMs)");
@@ -517,15 +535,16 @@ extern "C" int dn_mlp_weight_grad(const dn_mlp_desc* desc, int precision, const 
   p.grads = static_cast<const char*>(grads);
   p.act_pieces = t.act_pieces; p.grad_pieces = t.grad_pieces;
   p.n_points = n_points;
-  p.g_slot = g_slot; p.n_tiles_n = n_out / 32;
+  p.g_slot = g_slot; p.n_tiles_n = n_out / 32; p.custom_rows = custom_rows;
   p.x_slot = x_slot; p.x_tiles = x_width / 32;
   p.pe_slot = pe_kind == 1 ? t.slot_xyz : t.slot_dir;
   p.pe_tiles = pe_kind == 0 ? 0 : (pe_kind == 1 ? t.kxp : t.kdp) / 2;
   p.pe_L = pe_kind == 1 ? desc->num_encoding_fn_xyz : desc->num_encoding_fn_dir;
   p.dW = dW; p.ldw = ldw; p.col_pe0 = x_width; p.db = db;
-  DN_REQUIRE(p.n_tiles_n == 8 || p.n_tiles_n == 4 || p.n_tiles_n == 2, "dn_mlp_weight_grad: n_out must be 256, 128 or 64");
+  DN_REQUIRE(p.n_tiles_n == 8 || p.n_tiles_n == 4 || p.n_tiles_n == 2 || p.n_tiles_n == 1,
+             "dn_mlp_weight_grad: n_out must be 256, 128, 64 or < 32 (custom output gradient)");
   DN_REQUIRE(p.x_tiles + p.pe_tiles + 1 <= kWgMaxKTiles * (8 / p.n_tiles_n), "dn_mlp_weight_grad: too many input columns");
-  const int n_pieces = 2 * (p.n_tiles_n + p.x_tiles + p.pe_tiles);
+  const int n_pieces = (custom_rows ? 1 : 2 * p.n_tiles_n) + 2 * (p.x_tiles + p.pe_tiles);
   const size_t lds = static_cast<size_t>(2) * n_pieces * kPieceBytes;
   static thread_local bool attr_set = false;
   if (!attr_set) {

@@ -35,6 +35,7 @@ def _slots(model, precision):
     g["feat"] = (kh // 2) if model.use_viewdirs else 0
     g["trunk0"] = g["feat"] + (kh if model.use_viewdirs else 0)
     g["layer1"] = g["trunk0"] + (d - 1) * kh
+    g["out"] = g["layer1"] + kh
     return s, g, kh
 
 
@@ -94,11 +95,11 @@ class FusedNetFn(torch.autograd.Function):
                 x_slot = slots["trunk0"] + i * kh
             if model.use_viewdirs:
                 native(model.fc_feat, gslots["feat"], w, x_slot, w, 0)
-                put(model.fc_alpha, g_out[:, 3:4], act_hidden(x_slot, w))
+                native(model.fc_alpha, gslots["out"] + 1, 1, x_slot, w, 0)
                 native(model.layers_dir[0], gslots["dirout"], w // 2, slots["feat"], w, 2)
-                put(model.fc_rgb, g_out[:, :3], act_hidden(slots["dirout"], w // 2))
+                native(model.fc_rgb, gslots["out"], 3, slots["dirout"], w // 2, 0)
             else:
-                put(model.fc_out, g_out, act_hidden(x_slot, w))
+                native(model.fc_out, gslots["out"], 4, x_slot, w, 0)
             flat = []
             for m in model.linear_modules():
                 flat.extend(results[m])

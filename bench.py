@@ -88,7 +88,49 @@ def time_dominant_kernel(models, ro, rd, precision, reps=5):
     return t, flops / t / 1e12
 
 
-def cpu_baseline(sample_rays=4096):
+def pmc_traffic(precision):
+    """HBM bytes per fine-net launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE, profiles/r01_pmc_fine_net.json); bench.py itself cannot run the profiler."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_fine_net.json")
+    if precision != "bf16" or not os.path.exists(path):
+        return None
+    return json.load(open(path))["hbm_bytes_per_launch"]
+
+
+def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8):
+    """Secondary metric (SURVEY.md section 8d ii): rays/s of a full training iteration (perturbed sampling, density
+    noise, forward + backward + Adam) on n_rays random rays of the view."""
+    import nerf
+    dev = ro.device
+    cfg.nerf.train.perturb = True
+    cfg.nerf.train.radiance_field_noise_std = 0.2
+    cfg.nerf.train.chunksize = n_rays
+    params = list(models[0].parameters()) + list(models[1].parameters())
+    opt = torch.optim.Adam(params, lr=5e-4)
+    ro_f, rd_f = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    target = torch.rand(H * W, 3, device=dev)
+
+    def step():
+        sel = torch.randint(0, H * W, (n_rays,), device=dev)
+        out = nerf.run_one_iter_of_nerf(H, W, 1.0, models[0], models[1], ro_f[sel], rd_f[sel], cfg, mode="train",
+                                        encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=M_THRES)
+        loss = nerf.img2mse(out[0], target[sel]) + nerf.img2mse(out[3], target[sel])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"rays_per_s": n_rays / dt, "ms_per_step": dt * 1e3, "rays_per_step": n_rays,
+            "what": "fwd+bwd+Adam, 64+128 samples, perturb + noise 0.2, D8/W256 x2, fused HIP training kernels"}
+
+
+def cpu_baseline(sample_rays=16384):
     """The CPU oracle (a restatement of the reference's PyTorch path, pinned to goldens captured from the
     reference) timed on this box's host cores on a bounded sample of the same workload."""
     from nerf import synthetic as syn
@@ -120,6 +162,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-iteration measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,7 +227,7 @@ def main():
                                    "validation mode (det. resampling, no noise)",
                        "rays_per_step_per_gpu": H * W, "sharding": f"{world} ranks x own view (no collective in the path)"},
             "roofline": {"bound": "mfma", "achieved": ktf, "peak": peak, "unit": "TFLOP/s", "frac": ktf / peak,
-                         "traffic": None, "kernel": "mlp_forward_kernel<256,10,4> (fine net, 160000x192 points)",
+                         "traffic": pmc_traffic(args.precision), "kernel": "mlp_forward_kernel<256,10,4> (fine net, 160000x192 points)",
                          "kernel_ms": kt * 1e3, "whole_path_tflops": whole_tf},
         }
         if not args.no_cpu_baseline:
@@ -194,6 +237,8 @@ def main():
             mse = float(np.mean((rgb - ref[3].numpy()) ** 2))
             result["psnr_vs_oracle_db"] = float(-10.0 * np.log10(max(mse, 1e-12)))
             result["gpu_over_cpu"] = value / world / cb["value"]
+        if not args.no_train:
+            result["train"] = train_rate(models, cfg, ro, rd, ex, ed)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -61,6 +61,7 @@ extern "C" int dn_render_rays(const dn_mlp_desc* desc_coarse, const void* packed
                               const float* noise_c, const float* u, const float* noise_f, float* rgb_c,
                               float* depth_c, float* acc_c, float* rgb_f, float* depth_f, float* acc_f, float* dex_f,
                               void* workspace, dn_stream_t stream) {
+  if (n_rays == 0) return 0;
   DN_REQUIRE(desc_coarse && packed_coarse && rays && workspace && n_rays >= 0, "dn_render_rays: bad arguments");
   DN_REQUIRE(num_fine == 0 || (desc_fine && packed_fine), "dn_render_rays: fine pass requested without a fine net");
   DN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "dn_render_rays: workspace must be 256-byte aligned");

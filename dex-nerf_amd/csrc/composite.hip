@@ -202,6 +202,7 @@ extern "C" int dn_volume_render(const float* rf, const float* z, const float* rd
                                 float noise_std, int white_background, const float* h_m_thres, int n_thres,
                                 int64_t n_rays, int n_samples, float* rgb, float* disp, float* acc, float* weights,
                                 float* depth, float* dex, dn_stream_t stream) {
+  if (n_rays == 0) return 0;
   DN_REQUIRE(rf && z && rd && n_rays >= 0 && n_samples >= 1 && rd_stride >= 3, "dn_volume_render: bad arguments");
   DN_REQUIRE(n_thres >= 0 && n_thres <= kMaxThres, "dn_volume_render: at most %d Dex thresholds", kMaxThres);
   DN_REQUIRE(n_thres == 0 || (h_m_thres && dex), "dn_volume_render: thresholds given without dex output");
@@ -221,6 +222,7 @@ extern "C" int dn_volume_render_backward(const float* rf, const float* z, const 
                                          int n_samples, const float* g_rgb, const float* g_depth, const float* g_acc,
                                          const float* g_disp, const float* g_weights, float* g_rf,
                                          dn_stream_t stream) {
+  if (n_rays == 0) return 0;
   DN_REQUIRE(rf && z && rd && g_rf && n_rays >= 0 && n_samples >= 1 && rd_stride >= 3,
              "dn_volume_render_backward: bad arguments");
   DN_REQUIRE(n_samples <= 1024, "dn_volume_render_backward: at most 1024 samples per ray");

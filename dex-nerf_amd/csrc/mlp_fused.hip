@@ -524,6 +524,7 @@ extern "C" int dn_run_network(const dn_mlp_desc* desc, int precision, const void
   FwdParams p;
   int rc = setup_params(desc, precision, packed, &p);
   if (rc) return rc;
+  if (n_rays == 0) return 0;
   DN_REQUIRE(packed && out && n_rays >= 0 && samples_per_ray >= 1, "dn_run_network: bad arguments");
   DN_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "dn_run_network: out must be 16-byte aligned");
   if (pts != nullptr) {
@@ -546,6 +547,7 @@ extern "C" int dn_mlp_forward_encoded(const dn_mlp_desc* desc, int precision, co
   FwdParams p;
   int rc = setup_params(desc, precision, packed, &p);
   if (rc) return rc;
+  if (n_rows == 0) return 0;
   DN_REQUIRE(packed && x && out && n_rows >= 0, "dn_mlp_forward_encoded: bad arguments");
   DN_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "dn_mlp_forward_encoded: out must be 16-byte aligned");
   p.mode = 2; p.enc = x;

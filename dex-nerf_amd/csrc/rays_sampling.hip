@@ -282,8 +282,8 @@ extern "C" int dn_ray_bundle(int height, int width, const float* h_rinv9, const 
 
 extern "C" int dn_coarse_depths(const float* rays, int ray_stride, int64_t n_rays, int num_coarse, int lindisp,
                                 const float* t_rand, float* z_vals, dn_stream_t stream) {
+  if (n_rays == 0) return 0;  // empty tensors carry NULL data pointers
   DN_REQUIRE(rays && z_vals && n_rays >= 0 && num_coarse >= 1 && ray_stride >= 8, "dn_coarse_depths: bad arguments");
-  if (n_rays == 0) return 0;
   const int64_t total = n_rays * num_coarse;
   const int block = 256;
   const unsigned grid = static_cast<unsigned>((total + block - 1) / block);
@@ -308,6 +308,7 @@ void fill_freqs(float* f, int num_fns, int log_sampling) {
 
 extern "C" int dn_positional_encoding(const float* x, int64_t n_points, int dim, int num_fns, int include_input,
                                       int log_sampling, float* out, dn_stream_t stream) {
+  if (n_points == 0) return 0;
   DN_REQUIRE(x && out && n_points >= 0 && dim >= 1 && num_fns >= 0 && num_fns <= 32,
              "dn_positional_encoding: bad arguments (num_fns must be in [0,32])");
   DN_REQUIRE(include_input || num_fns > 0, "dn_positional_encoding: empty encoding");
@@ -324,6 +325,7 @@ extern "C" int dn_positional_encoding(const float* x, int64_t n_points, int dim,
 
 extern "C" int dn_sample_pdf(const float* bins, const float* weights, const float* u, int64_t n_rays, int n_bins,
                              int n_samples, float* samples, int64_t* inds, dn_stream_t stream) {
+  if (n_rays == 0) return 0;
   DN_REQUIRE(bins && weights && samples && n_rays >= 0 && n_samples >= 1, "dn_sample_pdf: bad arguments");
   DN_REQUIRE(n_bins >= 9 && n_bins <= 512, "dn_sample_pdf: n_bins must be in [9, 512] (weights row >= 8 wide)");
   if (n_rays == 0) return 0;
@@ -336,6 +338,7 @@ extern "C" int dn_sample_pdf(const float* bins, const float* weights, const floa
 
 extern "C" int dn_fine_depths(const float* z_coarse, const float* weights, const float* u, int64_t n_rays,
                               int num_coarse, int num_fine, float* z_fine, float* z_samples, dn_stream_t stream) {
+  if (n_rays == 0) return 0;
   DN_REQUIRE(z_coarse && weights && z_fine && n_rays >= 0 && num_fine >= 1, "dn_fine_depths: bad arguments");
   DN_REQUIRE(num_coarse >= 10 && num_coarse <= 512 && num_coarse + num_fine <= 2048,
              "dn_fine_depths: need 10 <= num_coarse <= 512 and num_coarse + num_fine <= 2048");

@@ -442,3 +442,71 @@ def test_fused_training_kernels(golden, dev, monkeypatch):
             print(f"{name} {k}: bf16-vs-fp32 gradient cosine {cos_bf:.4f}")
             assert cos_bf > 0.95, (name, k, cos_bf)  # measured 0.96-1.00: bf16 activations and gradients, fp32 accumulate
     assert len(calls) == 4
+
+
+@pytest.mark.parametrize("n_rays,nc,nf,lindisp,white,perturb", [
+    (1, 64, 128, False, False, False),      # a single ray
+    (37, 10, 7, False, True, False),        # minimum coarse count (weights row of 8), odd fine count, ragged ray count
+    (37, 33, 70, True, False, True),        # nothing a multiple of 32/64; lindisp; perturbed with injected draws
+    (19, 128, 256, False, False, False),    # BASELINE config 5 sampling (128 + 256 = 384 samples: 6 chunks of 64)
+    (130, 64, 0, False, True, False),       # coarse only (num_fine = 0): superset behaviour
+])
+def test_ragged_and_extreme_shapes_against_oracle(dev, n_rays, nc, nf, lindisp, white, perturb, monkeypatch):
+    """Edge shapes through the whole path (4x128 lego nets), HIP vs the CPU oracle on the same inputs."""
+    import nerf
+    from golden_cases import D4, lego_weights
+    from oracle import nerf_oracle as oc
+    rng = np.random.default_rng(n_rays * 1000 + nc)
+    sd_c, sd_f = lego_weights()
+    mc, mf = make_models(D4, sd_c, sd_f, dev)
+    ro = torch.from_numpy(rng.normal(0, 0.3, size=(n_rays, 3)).astype(np.float32) + np.array([0, 0, 4], np.float32))
+    rd = torch.from_numpy(rng.normal(0, 0.2, size=(n_rays, 3)).astype(np.float32) + np.array([0, 0, -1], np.float32))
+    rkw = dict(num_coarse=nc, num_fine=nf, near=2.0, far=6.0, lindisp=lindisp, white_background=white, perturb=perturb,
+               noise_std=0.1 if perturb else 0.0)
+    draws = None
+    if perturb:
+        draws = dict(t_rand=torch.from_numpy(rng.uniform(size=(n_rays, nc)).astype(np.float32)),
+                     noise_c=torch.from_numpy(rng.normal(size=(n_rays, nc)).astype(np.float32)),
+                     u=torch.from_numpy(rng.uniform(size=(n_rays, nf)).astype(np.float32)),
+                     noise_f=torch.from_numpy(rng.normal(size=(n_rays, nc + nf)).astype(np.float32)))
+        q_rand = [draws["t_rand"].to(dev), draws["u"].to(dev)]
+        q_randn = [draws["noise_c"].to(dev), draws["noise_f"].to(dev)]
+        monkeypatch.setattr(torch, "rand", lambda *a, **k: q_rand.pop(0))
+        monkeypatch.setattr(torch, "randn", lambda *a, **k: q_randn.pop(0))
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    thres = [5.0, 50.0, 500.0]
+    with torch.no_grad():
+        out = nerf.run_one_iter_of_nerf(1, n_rays, 1.0, mc, mf if nf > 0 else None, ro.to(dev), rd.to(dev), make_cfg(rkw),
+                                        mode="train", encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=thres)
+    cfg_o = oc.RenderCfg(chunksize=4096, m_thres=thres, **{k: v for k, v in rkw.items()})
+    mcfg = oc.ModelCfg(**D4)
+    with torch.no_grad():
+        ref = oc.run_one_iter(ro, rd, oc.to_torch_sd(sd_c), oc.to_torch_sd(sd_f) if nf > 0 else None, mcfg, mcfg, cfg_o, draws)
+    assert len(out) == len(ref) == 6 + len(thres)
+    for i in range(6):
+        if ref[i] is None:
+            assert out[i] is None
+            continue
+        assert out[i].shape == ref[i].shape
+        assert rel_err(C(out[i]), ref[i].numpy()) < TOL, i
+    dex = np.stack([C(o) for o in out[6:]])
+    dex_ref = np.stack([o.numpy() for o in ref[6:]])
+    assert (np.abs(dex - dex_ref) <= TOL * np.abs(dex_ref).max()).mean() > 0.98
+
+
+def test_empty_inputs(dev):
+    """Zero rays / zero points are legal and produce empty outputs, not launches."""
+    import nerf
+    from nerf import _ops
+    from golden_cases import D4, lego_weights
+    mc, mf = make_models(D4, *lego_weights(), dev)
+    rays = torch.zeros(0, 11, device=dev)
+    assert _ops.coarse_depths(rays, 64, False).shape == (0, 64)
+    z = torch.zeros(0, 64, device=dev)
+    assert _ops.run_network_rays(mc.packed(), rays, z).shape == (0, 64, 4)
+    out = _ops.volume_render_fwd(torch.zeros(0, 64, 4, device=dev), z, torch.zeros(0, 3, device=dev), None, 0.0, False, [5.0])
+    assert out[0].shape == (0, 3) and out[5].shape == (1, 0)
+    assert _ops.fine_depths(z, z, 128).shape == (0, 192)
+    r = _ops.render_rays(mc.packed(), mf.packed(), rays, 64, 128, False, 0.0, False, [5.0, 10.0])
+    assert r[3].shape == (0, 3) and r[6].shape == (2, 0)
+    assert nerf.positional_encoding(torch.zeros(0, 3, device=dev), 10).shape == (0, 63)

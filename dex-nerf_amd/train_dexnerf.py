@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Build-owned training / evaluation driver (counterpart of the reference's train_dexnerf_rgb.py:178-457 and
+eval_nerf.py:166-206) on the MI355X-native `nerf` package.
+
+What it keeps from the reference loop: one random training view per iteration, `num_random_rays` random pixels,
+loss = MSE(rgb_coarse) + MSE(rgb_fine), PSNR = mse2psnr(loss), Adam with the per-iteration exponential LR
+`lr0 * factor^(i / (lr_decay * 1000))`, validation renders with the Dex threshold sweep
+(`m_thres_cand = arange(5, m_thres + 5, 5)`, best threshold by mean |depth error| on the (0, 1.25 m] mask-style
+validity mask), and the checkpoint dict keys (iter, model_*_state_dict, optimizer_state_dict, loss, psnr).
+What it adds: data-parallel training (one process per GPU under torch.distributed.run; one flat-bucket gradient
+all-reduce per step) and a synthetic "teacher" scene, because no dataset ships with the reference: a fixed random
+coarse/fine FlexibleNeRFModel pair is rendered from spherical poses and the student learns to reproduce it.
+
+    python dex-nerf_amd/train_dexnerf.py --iters 2000 --size 100 --precision bf16
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 dex-nerf_amd/train_dexnerf.py ...
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+import nerf  # noqa: E402
+from nerf import parallel, synthetic as syn  # noqa: E402
+
+
+def make_cfg(args):
+    def mode(train):
+        return dict(chunksize=args.chunksize, lindisp=False, num_coarse=args.num_coarse, num_fine=args.num_fine,
+                    perturb=train, radiance_field_noise_std=args.noise_std if train else 0.0, white_background=False)
+    return nerf.CfgNode(dict(dataset=dict(near=2.0, far=6.0, no_ndc=True),
+                             nerf=dict(use_viewdirs=True, train=mode(True), validation=mode(False))))
+
+
+def build_models(kw, dev, state=None):
+    out = []
+    for i in range(2):
+        m = nerf.models.FlexibleNeRFModel(**kw)
+        if state is not None:
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in state[i].items()})
+        out.append(m.to(dev))
+    return out
+
+
+def render_view(models, cfg, pose, k_mat, size, ex, ed, thres, mode="validation"):
+    ro, rd = nerf.get_ray_bundle(size, size, float(k_mat[0, 0]), pose, k_mat)
+    with torch.no_grad():
+        return nerf.run_one_iter_of_nerf(size, size, float(k_mat[0, 0]), models[0], models[1], ro, rd, cfg, mode=mode,
+                                         encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=thres)
+
+
+def dex_sweep(outputs, depth_gt, thres):
+    """Pick the Dex threshold with the smallest mean |depth error| (reference train_dexnerf_rgb.py:391-408)."""
+    mask = (depth_gt > 0) & (depth_gt < 6.0)
+    best = None
+    for m, depth in zip(thres, outputs[6:]):
+        err = nerf.compute_err_metric(depth_gt[None], depth[None], mask[None])
+        if best is None or err["depth_abs_err"] < best[1]["depth_abs_err"]:
+            best = (m, err)
+    return best
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=2000)
+    ap.add_argument("--size", type=int, default=100, help="image height = width of the synthetic views")
+    ap.add_argument("--views", type=int, default=20)
+    ap.add_argument("--num-random-rays", type=int, default=2048)
+    ap.add_argument("--num-coarse", type=int, default=64)
+    ap.add_argument("--num-fine", type=int, default=128)
+    ap.add_argument("--chunksize", type=int, default=65536)
+    ap.add_argument("--noise-std", type=float, default=0.2)
+    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--lr", type=float, default=5e-4)
+    ap.add_argument("--lr-decay", type=int, default=250)
+    ap.add_argument("--lr-decay-factor", type=float, default=0.1)
+    ap.add_argument("--m-thres", type=int, default=100)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--validate-every", type=int, default=500)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--save", default="", help="checkpoint path (reference dict format)")
+    ap.add_argument("--load-checkpoint", default="")
+    ap.add_argument("--quiet", action="store_true")
+    args = ap.parse_args(argv)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    np.random.seed(args.seed + rank)          # reference seeds np + torch from cfg.experiment.randomseed (:97-99)
+    torch.manual_seed(args.seed + rank)
+    nerf.set_precision(args.precision)
+
+    kw = dict(num_layers=args.layers, hidden_size=args.width, skip_connect_every=4, num_encoding_fn_xyz=10,
+              num_encoding_fn_dir=4, use_viewdirs=True)
+    cfg = make_cfg(args)
+    ex, ed = nerf.get_embedding_function(10, True, True), nerf.get_embedding_function(4, True, True)
+    thres = np.arange(5, args.m_thres + 5, 5)
+    k_mat = torch.from_numpy(syn.intrinsic(args.size, args.size)).to(dev)
+    poses = [torch.from_numpy(syn.scene_pose(i, n_views=args.views + 1)).to(dev) for i in range(args.views + 1)]
+
+    # ---- synthetic dataset: a fixed teacher field rendered from every pose (last pose is held out) ----
+    teacher = build_models(kw, dev, (syn.synth_state_dict(42, sigma_bias=-150.0, **kw), syn.synth_state_dict(43, sigma_bias=-20.0, **kw)))
+    images, depths = [], []
+    for pose in poses:
+        out = render_view(teacher, cfg, pose, k_mat, args.size, ex, ed, thres)
+        images.append(out[3].reshape(-1, 3))
+        depths.append(out[4].reshape(args.size, args.size))
+    del teacher
+
+    torch.manual_seed(args.seed)              # identical student init on every rank
+    student = build_models(kw, dev)
+    parallel.broadcast_parameters(student)
+    torch.manual_seed(args.seed + 1000 + rank)
+    bucket = parallel.FlatGradBucket(student)
+    opt = torch.optim.Adam(bucket.params, lr=args.lr)
+    start = 0
+    if args.load_checkpoint:
+        ck = torch.load(args.load_checkpoint, map_location=dev)
+        student[0].load_state_dict(ck["model_coarse_state_dict"])
+        student[1].load_state_dict(ck["model_fine_state_dict"])
+        opt.load_state_dict(ck["optimizer_state_dict"])
+        start = ck["iter"]
+    train_ids = list(range(args.views))[rank::world] or [rank % args.views]
+    history = []
+    t0 = time.perf_counter()
+    loss_val = psnr = float("nan")
+    for it in range(start, args.iters):
+        view = int(np.random.choice(train_ids))
+        ro, rd = nerf.get_ray_bundle(args.size, args.size, float(k_mat[0, 0]), poses[view], k_mat)
+        sel = torch.from_numpy(np.random.choice(args.size * args.size, size=min(args.num_random_rays, args.size ** 2),
+                                                replace=False)).to(dev)
+        out = nerf.run_one_iter_of_nerf(args.size, args.size, float(k_mat[0, 0]), student[0], student[1],
+                                        ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel], cfg, mode="train",
+                                        encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=thres)
+        target = images[view][sel]
+        loss = nerf.img2mse(out[0][..., :3], target) + nerf.img2mse(out[3][..., :3], target)
+        bucket.zero()
+        loss.backward()
+        bucket.all_reduce_mean()              # one flat all-reduce (RCCL over xGMI when world > 1)
+        opt.step()
+        lr = args.lr * args.lr_decay_factor ** (it / (args.lr_decay * 1000))   # train_dexnerf_rgb.py:284-289
+        for group in opt.param_groups:
+            group["lr"] = lr
+        if it % 100 == 0 or it == args.iters - 1:
+            loss_val = loss.item()
+            psnr = nerf.mse2psnr(loss_val)
+            history.append((it, loss_val, psnr))
+            if rank == 0 and not args.quiet:
+                print(f"[train] iter {it:6d} loss {loss_val:.5f} psnr {psnr:.2f} dB lr {lr:.2e} "
+                      f"{(time.perf_counter() - t0):.1f} s", flush=True)
+        if rank == 0 and args.validate_every and (it + 1) % args.validate_every == 0:
+            out = render_view(student, cfg, poses[-1], k_mat, args.size, ex, ed, thres)
+            vmse = nerf.img2mse(out[3].reshape(-1, 3), images[-1]).item()
+            m_best, err = dex_sweep(out, depths[-1], thres)
+            if not args.quiet:
+                print(f"[val]   iter {it + 1:6d} held-out view psnr {nerf.mse2psnr(vmse):.2f} dB; Dex best m={m_best} "
+                      f"abs depth err {err['depth_abs_err']:.1f} mm", flush=True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    result = dict(history=history, final_loss=loss_val, final_psnr=psnr, seconds=elapsed,
+                  rays_per_s=world * args.num_random_rays * (args.iters - start) / max(elapsed, 1e-9))
+    if rank == 0:
+        out = render_view(student, cfg, poses[-1], k_mat, args.size, ex, ed, thres)
+        result["val_psnr"] = nerf.mse2psnr(nerf.img2mse(out[3].reshape(-1, 3), images[-1]).item())
+        if args.save:
+            torch.save({"iter": args.iters, "model_coarse_state_dict": student[0].state_dict(),
+                        "model_fine_state_dict": student[1].state_dict(), "optimizer_state_dict": opt.state_dict(),
+                        "loss": loss_val, "psnr": psnr}, args.save)
+        if not args.quiet:
+            print(f"[done] {args.iters - start} iters in {elapsed:.1f} s = {result['rays_per_s']:.0f} rays/s; "
+                  f"held-out psnr {result['val_psnr']:.2f} dB", flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

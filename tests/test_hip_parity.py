@@ -510,3 +510,20 @@ def test_empty_inputs(dev):
     r = _ops.render_rays(mc.packed(), mf.packed(), rays, 64, 128, False, 0.0, False, [5.0, 10.0])
     assert r[3].shape == (0, 3) and r[6].shape == (2, 0)
     assert nerf.positional_encoding(torch.zeros(0, 3, device=dev), 10).shape == (0, 63)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_training_driver_learns_a_synthetic_scene(dev, precision):
+    """End-to-end: the build-owned driver (reference loop: random view + random rays, MSE_c + MSE_f, Adam with the
+    exponential LR, Dex threshold sweep) trains a 4x128 student on a teacher scene through the fused HIP training
+    kernels; the training PSNR must rise by > 10 dB in 300 iterations and the held-out view must follow."""
+    import nerf
+    import train_dexnerf
+    try:
+        res = train_dexnerf.main(["--iters", "300", "--size", "32", "--views", "6", "--num-random-rays", "512", "--layers", "4",
+                                  "--width", "128", "--validate-every", "0", "--quiet", "--precision", precision])
+    finally:
+        nerf.set_precision("fp32")
+    first, last = res["history"][0], res["history"][-1]
+    assert last[2] - first[2] > 10.0, (first, last)
+    assert res["val_psnr"] > 18.0, res["val_psnr"]

@@ -25,7 +25,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 constexpr int kRingPhases = 5;
 constexpr int kSlotBytes = kPhasePieces * kPieceBytes;  // 16 KiB
 constexpr int kRingBytes = kRingPhases * kSlotBytes;    // 80 KiB
-constexpr int kPrefetch = 4;                            // A-fragment pieces read ahead of the MFMA that uses them
+#ifndef DN_PREFETCH
+#define DN_PREFETCH 4
+#endif
+constexpr int kPrefetch = DN_PREFETCH;                  // A-fragment pieces read ahead of the MFMA that uses them
 constexpr int kInRows = 10;                             // per-wave input staging rows
 
 template <bool BF16> struct Prec;
@@ -248,6 +251,9 @@ __device__ __forceinline__ void run_stage(PipeT& pipe, const BH& bh /* [PT][KH] 
       a[t][8] = b2[0]; a[t][9] = b2[1]; a[t][10] = b2[2]; a[t][11] = b2[3];
       a[t][12] = b3[0]; a[t][13] = b3[1]; a[t][14] = b3[2]; a[t][15] = b3[3];
     }
+#ifdef DN_EXP_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
     static_for<KT>([&](auto k_c) {
       constexpr int k = decltype(k_c)::value;
       constexpr int pos = POS0 + nt * KT + k;
@@ -260,10 +266,15 @@ __device__ __forceinline__ void run_stage(PipeT& pipe, const BH& bh /* [PT][KH] 
         else a[t] = mma_piece<BF16>(a[t], araw, bp(t, k - KH));
       });
       pipe.template prefetch<pos>();
+#ifndef DN_EXP_NOPIN
       // pin the interleave: the MFMAs of this piece, then the one LDS read that refills its FIFO slot
       __builtin_amdgcn_sched_group_barrier(0x008, (BF16 ? 1 : 4) * PT, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#endif
     });
+#ifdef DN_EXP_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // region boundary BEFORE the epilogue: emit(nt)'s VALU work may overlap tile nt+1's MFMAs, but whole tiles
     // are not interleaved (that would keep several accumulator tiles live and spill)
     __builtin_amdgcn_sched_barrier(0);

@@ -28,7 +28,8 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
   using BPiece = typename P::BPiece;
   constexpr int NT = W / 32;
   constexpr int KH = NT * P::PPT;                      // hidden pieces of a W-wide input
-  constexpr int KXP = round_up(3 + 6 * LX, 16) / (2 * P::EPP);  // PE xyz pieces
+  constexpr int KXP = kXyzPanel / (2 * P::EPP);                 // PE xyz pieces (fixed 64-wide panel)
+  static_assert(3 + 6 * LX <= kXyzPanel, "xyz encoding wider than its K panel");
   constexpr int KDP = round_up(3 + 6 * LD, 16) / (2 * P::EPP);  // PE dir pieces
   constexpr int WAVES = waves_of<BF16, PT>();
   constexpr int PTS_PER_WAVE = 32 * PT;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
 template <bool BF16>
 __global__ void pack_kernel(NetLayout L, PackPtrs ptrs, char* __restrict__ packed) {  // also used by mlp_train.hip
   using P = Prec<BF16>;
-  const int KX = round_up(3 + 6 * L.LX, 16), KD = round_up(3 + 6 * L.LD, 16);
+  const int KX = kXyzPanel, KD = round_up(3 + 6 * L.LD, 16);
   (void)KX; (void)KD;
   // bias tiles
   const int n_bias = L.total_bias_tiles * 32;
@@ -416,7 +417,7 @@ static int launch_forward(FwdParams p, hipStream_t stream) {
   auto kern = mlp_forward_kernel<W, LX, LD, BF16, PT, SAVE>;
   constexpr int WAVES = waves_of<BF16, PT>();
   constexpr int PTS_PER_WG = WAVES * 32 * PT;
-  constexpr int KXP = round_up(3 + 6 * LX, 16) / (2 * Prec<BF16>::EPP);
+  constexpr int KXP = kXyzPanel / (2 * Prec<BF16>::EPP);
   p.n_tiles = (p.n_points + PTS_PER_WG - 1) / PTS_PER_WG;
   constexpr int KDP = round_up(3 + 6 * LD, 16) / (2 * Prec<BF16>::EPP);
   const size_t lds = kRingBytes + p.bias_bytes + WAVES * (kInRows * 32 * PT * sizeof(float) + PT * (KXP + KDP) * kPieceBytes);
@@ -448,11 +449,10 @@ int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStrea
     return DN_E_UNSUPPORTED;
   }
 #define DN_CASE(W_, LX_)                                                                     \
-  if (d.hidden_size == W_ && d.num_encoding_fn_xyz == LX_) {                                 \
-    if (!bf) return launch_forward<W_, LX_, 4, false, 1>(p, stream);                         \
-    return bf16_pt == 1 ? launch_forward<W_, LX_, 4, true, 1>(p, stream)                     \
-                        : launch_forward<W_, LX_, 4, true, 2>(p, stream);                    \
-  }
+  if (d.hidden_size == W_ && d.num_encoding_fn_xyz == LX_)                                   \
+    return bf ? launch_forward<W_, LX_, 4, true, 1>(p, stream) : launch_forward<W_, LX_, 4, false, 1>(p, stream);
+  if (bf && bf16_pt == 2 && d.hidden_size == 256 && d.num_encoding_fn_xyz == 10)
+    return launch_forward<256, 10, 4, true, 2>(p, stream);  // experimental 4-wave x 64-point geometry
   DN_CASE(256, 10)
   DN_CASE(128, 10)
   DN_CASE(256, 6)

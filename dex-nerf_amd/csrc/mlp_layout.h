@@ -23,6 +23,11 @@ constexpr int kMaxStages = 40;
 
 __host__ __device__ constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// Padded width of the xyz positional encoding as a K panel.  Fixed at 64 (L_xyz <= 10) rather than round_up(3+6L,16):
+// every stage then holds a multiple of 16 pieces for W in {128, 256}, so the trunk stages all start on a pipeline
+// phase boundary (an L=6 panel of 48 would leave W=128 stages at 12 / 24 pieces).
+constexpr int kXyzPanel = 64;
+
 // Row of a 32x32 accumulator tile held in register r of a lane in half h (C/D layout of the 32x32 MFMAs).
 __host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -71,7 +76,7 @@ struct NetLayout {
 inline int build_layout(const dn_mlp_desc& d, int precision, NetLayout* out) {
   const int kpp = (precision == DN_PREC_BF16) ? 16 : 8;
   const int W = d.hidden_size, D = d.num_layers;
-  const int KX = round_up(3 + 6 * d.num_encoding_fn_xyz, 16);
+  const int KX = kXyzPanel;
   const int KD = round_up(3 + 6 * d.num_encoding_fn_dir, 16);
   const int DX = 3 + 6 * d.num_encoding_fn_xyz, DD = 3 + 6 * d.num_encoding_fn_dir;
   NetLayout& L = *out;
@@ -131,7 +136,7 @@ inline void build_train_layout(const dn_mlp_desc& d, int precision, TrainLayout*
   const bool bf = precision == DN_PREC_BF16;
   t->kpp = bf ? 16 : 8; t->epp = bf ? 8 : 4; t->ppt = bf ? 2 : 4;
   const int W = d.hidden_size, D = d.num_layers;
-  t->kxp = round_up(3 + 6 * d.num_encoding_fn_xyz, 16) / t->kpp;
+  t->kxp = kXyzPanel / t->kpp;
   t->kdp = d.use_viewdirs ? round_up(3 + 6 * d.num_encoding_fn_dir, 16) / t->kpp : 0;
   t->kh = W / t->kpp;
   int s = 0;

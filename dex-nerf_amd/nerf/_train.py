@@ -24,7 +24,7 @@ def _slots(model, precision):
     """Piece slots of the saved activations / gradients (mirrors TrainLayout in csrc/mlp_layout.h)."""
     kpp = 16 if precision == _hip.PREC_BF16 else 8
     w, d = model.hidden_size, model.num_layers
-    kxp = ((model.dim_xyz + 15) // 16 * 16) // kpp
+    kxp = 64 // kpp   # fixed 64-wide xyz panel (kXyzPanel in csrc/mlp_layout.h)
     kdp = (((model.dim_dir + 15) // 16 * 16) // kpp) if model.use_viewdirs else 0
     kh = w // kpp
     s = {"xyz": 0, "dir": kxp, "layer1": kxp + kdp}

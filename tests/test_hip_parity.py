@@ -527,3 +527,27 @@ def test_training_driver_learns_a_synthetic_scene(dev, precision):
     first, last = res["history"][0], res["history"][-1]
     assert last[2] - first[2] > 10.0, (first, last)
     assert res["val_psnr"] > 18.0, res["val_psnr"]
+
+
+@pytest.mark.parametrize("width,l_xyz,viewdirs", [(128, 6, True), (256, 6, True), (128, 10, False), (128, 6, False)])
+def test_fused_network_other_instances(dev, width, l_xyz, viewdirs):
+    """Kernel instances the goldens do not exercise (L_xyz = 6 defaults of FlexibleNeRFModel, the fc_out head at W=128
+    whose stream is padded mid-phase): fused kernel vs the nn.Linear composition fed by the HIP encoding kernel."""
+    import nerf
+    torch.manual_seed(5)
+    m = nerf.models.FlexibleNeRFModel(num_layers=5, hidden_size=width, skip_connect_every=2, num_encoding_fn_xyz=l_xyz,
+                                      num_encoding_fn_dir=4, use_viewdirs=viewdirs).to(dev)
+    n, s = 21, 40
+    pts = torch.randn(n, s, 3, device=dev) * 1.5
+    vd = torch.nn.functional.normalize(torch.randn(n, 3, device=dev), dim=-1)
+    rays = torch.cat([torch.zeros(n, 8, device=dev), vd], -1)
+    ex, ed = nerf.get_embedding_function(l_xyz), (nerf.get_embedding_function(4) if viewdirs else None)
+    with torch.no_grad():
+        fused = nerf.run_network(m, pts, rays, 4096, ex, ed)
+        emb = ex(pts.reshape(-1, 3))
+        if viewdirs:
+            emb = torch.cat([emb, ed(vd[:, None, :].expand(n, s, 3).reshape(-1, 3))], -1)
+        ref = m._forward_modules(emb).reshape(n, s, 4)
+        direct = m(emb).reshape(n, s, 4)   # FlexibleNeRFModel.forward(x) on embedded rows -> dn_mlp_forward_encoded
+    assert rel_err(C(fused), C(ref)) < TOL
+    assert rel_err(C(direct), C(ref)) < TOL

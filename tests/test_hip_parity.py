@@ -551,3 +551,43 @@ def test_fused_network_other_instances(dev, width, l_xyz, viewdirs):
         direct = m(emb).reshape(n, s, 4)   # FlexibleNeRFModel.forward(x) on embedded rows -> dn_mlp_forward_encoded
     assert rel_err(C(fused), C(ref)) < TOL
     assert rel_err(C(direct), C(ref)) < TOL
+
+
+@pytest.mark.parametrize("depth,width,viewdirs", [(5, 128, False), (5, 128, True), (6, 256, False), (2, 128, True)])
+def test_fused_training_other_shapes(dev, depth, width, viewdirs):
+    """Fused training path on shapes the goldens do not cover: even/odd trunk depth (ping-pong pairs + tail), a skip
+    every 2 layers, the fc_out head (no view directions: custom 4-row output-gradient piece), the smallest trunk.
+    Parameter gradients vs PyTorch autograd over the same nn.Linear composition, fp32 and bf16."""
+    import nerf
+    from nerf import _train
+    torch.manual_seed(11)
+    base = nerf.models.FlexibleNeRFModel(num_layers=depth, hidden_size=width, skip_connect_every=2, num_encoding_fn_xyz=10,
+                                         num_encoding_fn_dir=4, use_viewdirs=viewdirs).to(dev)
+    assert _train.train_fused_ok(base)
+    n, s = 19, 48
+    pts = torch.randn(n, s, 3, device=dev)
+    vd = torch.nn.functional.normalize(torch.randn(n, 3, device=dev), dim=-1)
+    rays = torch.cat([torch.zeros(n, 8, device=dev), vd], -1)
+    g_up = torch.randn(n, s, 4, device=dev)
+    ex, ed = nerf.get_embedding_function(10), (nerf.get_embedding_function(4) if viewdirs else None)
+    emb = ex(pts.reshape(-1, 3))
+    if viewdirs:
+        emb = torch.cat([emb, ed(vd[:, None, :].expand(n, s, 3).reshape(-1, 3))], -1)
+    (base._forward_modules(emb).reshape(n, s, 4) * g_up).sum().backward()
+    ref = {k: C(p.grad).astype(np.float64).reshape(-1) for k, p in base.named_parameters()}
+    for prec, cos_min, rel_max in (("fp32", 0.99999, 1e-3), ("bf16", 0.95, None)):
+        nerf.set_precision(prec)
+        try:
+            m = nerf.models.FlexibleNeRFModel(num_layers=depth, hidden_size=width, skip_connect_every=2,
+                                              num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=viewdirs).to(dev)
+            m.load_state_dict(base.state_dict())
+            out = nerf.run_network(m, pts, rays, 4096, ex, ed)
+            (out * g_up).sum().backward()
+            for k, p in m.named_parameters():
+                a = C(p.grad).astype(np.float64).reshape(-1)
+                cos = float(a @ ref[k] / max(np.linalg.norm(a) * np.linalg.norm(ref[k]), 1e-30))
+                assert cos > cos_min, (prec, k, cos)
+                if rel_max is not None:
+                    assert rel_err(a, ref[k]) < rel_max, (prec, k)
+        finally:
+            nerf.set_precision("fp32")

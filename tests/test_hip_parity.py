@@ -591,3 +591,34 @@ def test_fused_training_other_shapes(dev, depth, width, viewdirs):
                     assert rel_err(a, ref[k]) < rel_max, (prec, k)
         finally:
             nerf.set_precision("fp32")
+
+
+def test_render_is_hipgraph_capturable(golden, dev):
+    """The C ABI never allocates or synchronises, so a whole predict_and_render_radiance chunk (6 kernels) can be
+    captured into a hipGraph and replayed; the replay must reproduce the eager outputs bit for bit."""
+    from nerf import _ops
+    from oracle import nerf_oracle as oc
+    g = golden("render_lego_val")
+    mkw, wfn, rkw = CASES["render_lego_val"]
+    mc, mf = make_models(mkw, *wfn(), dev)
+    cfg = oc.RenderCfg(**rkw)
+    rays = oc.pack_rays(torch.from_numpy(g["ro"]), torch.from_numpy(g["rd"]), cfg).to(dev)
+    pc, pf = mc.packed(), mf.packed()
+    thres = [5.0, 10.0]
+    eager = _ops.render_rays(pc, pf, rays, 64, 64, False, 0.0, True, thres)   # also warms up (function attributes)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _ops.render_rays(pc, pf, rays, 64, 64, False, 0.0, True, thres)      # workspace for this stream
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            captured = _ops.render_rays(pc, pf, rays, 64, 64, False, 0.0, True, thres)
+    torch.cuda.current_stream().wait_stream(side)
+    for t in captured:
+        t.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(eager, captured):
+        assert torch.equal(a, b)

@@ -34,7 +34,7 @@ MODEL_KW = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encodin
 FLOP_PER_POINT = 1186816           # unpadded dims, SURVEY.md section 8d
 POINTS_PER_RAY = NC + (NC + NF)    # coarse net + fine net
 M_THRES = [float(m) for m in range(5, 105, 5)]
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 
 
 def build_scene(dev, rank):
@@ -160,7 +160,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-iteration measurement")
     args = ap.parse_args()
@@ -237,6 +237,21 @@ def main():
             mse = float(np.mean((rgb - ref[3].numpy()) ** 2))
             result["psnr_vs_oracle_db"] = float(-10.0 * np.log10(max(mse, 1e-12)))
             result["gpu_over_cpu"] = value / world / cb["value"]
+        if args.precision == "bf16" and not args.no_cpu_baseline:
+            # the same render in the fp16 MFMA mode (same matrix rate, 10-bit mantissa): informational
+            nerf.set_precision("fp16")
+            render(models, cfg, ro, rd, ex, ed)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                out16 = render(models, cfg, ro, rd, ex, ed)
+            torch.cuda.synchronize()
+            dt16 = (time.perf_counter() - t1) / 3
+            rgb16 = out16[3].reshape(-1, 3)[torch.from_numpy(sel).to(dev)].cpu().numpy()
+            mse16 = float(np.mean((rgb16 - ref[3].numpy()) ** 2))
+            result["fp16_mode"] = {"value": H * W / dt16, "unit": "rays/s",
+                                   "psnr_vs_oracle_db": float(-10.0 * np.log10(max(mse16, 1e-12)))}
+            nerf.set_precision(args.precision)
         if not args.no_train:
             result["train"] = train_rate(models, cfg, ro, rd, ex, ed)
         print(json.dumps(result), flush=True)

@@ -12,6 +12,7 @@ namespace dn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <int N, class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -31,14 +32,23 @@ constexpr int kRingBytes = kRingPhases * kSlotBytes;    // 80 KiB
 constexpr int kPrefetch = DN_PREFETCH;                  // A-fragment pieces read ahead of the MFMA that uses them
 constexpr int kInRows = 10;                             // per-wave input staging rows
 
-template <bool BF16> struct Prec;
-template <> struct Prec<true> {
+// arithmetic mode (the template parameter is still called BF16: 0 = fp32, 1 = bf16, 2 = fp16; non-zero = 16-bit MFMA)
+template <int BF16> struct Prec;
+template <> struct Prec<1> {
   using BPiece = bf16x8;
+  using Elem = __bf16;
   static constexpr int EPP = 8;    // k-values (elements) per lane per piece
   static constexpr int PPT = 2;    // pieces per 32-row hidden tile
 };
-template <> struct Prec<false> {
+template <> struct Prec<2> {   // fp16: same MFMA rate and layouts as bf16, 10-bit mantissa (render-only mode)
+  using BPiece = f16x8;
+  using Elem = _Float16;
+  static constexpr int EPP = 8;
+  static constexpr int PPT = 2;
+};
+template <> struct Prec<0> {
   using BPiece = f32x4;
+  using Elem = float;
   static constexpr int EPP = 4;
   static constexpr int PPT = 4;
 };
@@ -46,7 +56,7 @@ template <> struct Prec<false> {
 // SIMD.  bf16 PT=2 -> 4 waves x 64 points, one wave per SIMD (every A fragment read from LDS feeds two MFMAs;
 // halves the LDS read traffic but a lone wave per SIMD hides no stall - measured 4 % slower).  fp32: PT=1,
 // 4 waves x 32 points, one wave per SIMD.
-template <bool BF16, int PT> constexpr int waves_of() { return (BF16 && PT == 1) ? 8 : 4; }
+template <int BF16, int PT> constexpr int waves_of() { return (BF16 && PT == 1) ? 8 : 4; }
 
 struct FwdParams {
   const char* packed;   // [bias region][pieces]
@@ -212,11 +222,14 @@ struct Pipe {
   }
 };
 
-template <bool BF16>
+template <int BF16>
 __device__ __forceinline__ f32x16 mma_piece(f32x16 acc, f32x4 a_raw, typename Prec<BF16>::BPiece b) {
-  if constexpr (BF16) {
+  if constexpr (BF16 == 1) {
     const bf16x8 a = __builtin_bit_cast(bf16x8, a_raw);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  } else if constexpr (BF16 == 2) {
+    const f16x8 a = __builtin_bit_cast(f16x8, a_raw);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
   } else {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_raw[0], b[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_raw[1], b[1], acc, 0, 0, 0);
@@ -232,7 +245,7 @@ __device__ __forceinline__ f32x16 mma_piece(f32x16 acc, f32x4 a_raw, typename Pr
 // consumes them (ReLU + convert into the next stage's B pieces, or pick the output rows) while the next tile's
 // MFMAs are already being issued.  POS0 = piece position (mod 16) at which the stage starts; phase boundaries
 // (counted vmcnt + barrier + next DMA) are compile-time positions in the unrolled sequence.
-template <bool BF16, int PT, int NT_OUT, int KH, int KP, int POS0, bool HAS_BIAS = true, class PipeT, class BH, class BP, class Emit>
+template <int BF16, int PT, int NT_OUT, int KH, int KP, int POS0, bool HAS_BIAS = true, class PipeT, class BH, class BP, class Emit>
 __device__ __forceinline__ void run_stage(PipeT& pipe, const BH& bh /* [PT][KH] */, BP&& bp /* (t, k) -> PE piece */,
                                           const char* bias_lds /* this lane-half's 64 B of tile 0 */, Emit&& emit) {
   constexpr int KT = KH + KP;
@@ -285,13 +298,13 @@ __device__ __forceinline__ void run_stage(PipeT& pipe, const BH& bh /* [PT][KH] 
 // accumulator tile -> the next stage's B pieces (in the register-resident chain), optional ReLU.
 // bf16: convert first, then ReLU on the packed pairs as a signed-int16 max with 0 (a negative bf16 has its
 // sign bit set, i.e. is a negative int16; -0.0 -> +0.0): 4 v_pk_max_i16 instead of 8 v_max_f32 per piece.
-template <bool BF16, bool RELU, int S>
+template <int BF16, bool RELU, int S>
 __device__ __forceinline__ typename Prec<BF16>::BPiece make_piece(const f32x16& acc) {
   using P = Prec<BF16>;
   typename P::BPiece piece;
   if constexpr (BF16) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) piece[e] = static_cast<__bf16>(acc[S * 8 + e]);
+    for (int e = 0; e < 8; ++e) piece[e] = static_cast<typename P::Elem>(acc[S * 8 + e]);
     if constexpr (RELU) {
       typedef short s16x8 __attribute__((ext_vector_type(8)));
       s16x8 bits = __builtin_bit_cast(s16x8, piece);
@@ -306,7 +319,7 @@ __device__ __forceinline__ typename Prec<BF16>::BPiece make_piece(const f32x16& 
   return piece;
 }
 
-template <bool BF16, bool RELU, int NT, class BO>
+template <int BF16, bool RELU, int NT, class BO>
 __device__ __forceinline__ void emit_pieces(const f32x16& acc, BO& bo) {
   using P = Prec<BF16>;
   static_for<P::PPT>([&](auto s_c) {
@@ -318,7 +331,7 @@ __device__ __forceinline__ void emit_pieces(const f32x16& acc, BO& bo) {
 // ---- positional encoding straight into B-piece layout -------------------------------------------------
 // Slot u of this lane-half (mlp_layout.h pe_slot_col): u < 6*(L/2): sin/cos of this half's frequencies;
 // then identity (half 0: x, y; half 1: z); rest zero padding.
-template <bool BF16, int L, int NPIECES, class BP>
+template <int BF16, int L, int NPIECES, class BP>
 __device__ __forceinline__ void encode_pieces(const float (&x)[3], const float* freqs, int h, BP& bp) {
   using P = Prec<BF16>;
   constexpr int NF = L / 2;
@@ -350,14 +363,14 @@ __device__ __forceinline__ void encode_pieces(const float (&x)[3], const float* 
       else if constexpr (u == 6 * NF) v = h ? x[2] : x[0];
       else if constexpr (u == 6 * NF + 1) v = h ? 0.0f : x[1];
       else v = 0.0f;
-      if constexpr (BF16) piece[e] = static_cast<__bf16>(v); else piece[e] = v;
+      piece[e] = static_cast<typename P::Elem>(v);
     });
     bp[p] = piece;
   });
 }
 
 // Encoded-rows input (FlexibleNeRFModel.forward(x) call surface): gather this lane's slots from x.
-template <bool BF16, int L, int NPIECES, class BP>
+template <int BF16, int L, int NPIECES, class BP>
 __device__ __forceinline__ void gather_pieces(const float* row, int h, BP& bp) {
   using P = Prec<BF16>;
   static_for<NPIECES>([&](auto p_c) {
@@ -367,7 +380,7 @@ __device__ __forceinline__ void gather_pieces(const float* row, int h, BP& bp) {
     for (int e = 0; e < P::EPP; ++e) {
       const int col = pe_slot_col(L, h, p * P::EPP + e);
       const float v = (col >= 0) ? row[col] : 0.0f;
-      if constexpr (BF16) piece[e] = static_cast<__bf16>(v); else piece[e] = v;
+      piece[e] = static_cast<typename P::Elem>(v);
     }
     bp[p] = piece;
   });

@@ -22,7 +22,7 @@ namespace dn {
 
 // SAVE = training forward: every stage's output pieces (and both encodings) are also written to `p.act` in the
 // wave-native piece layout, plus one 128-bit ReLU mask word per lane per masked stage to `p.masks`.
-template <int W, int LX, int LD, bool BF16, int PT, bool SAVE>
+template <int W, int LX, int LD, int BF16, int PT, bool SAVE>
 __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2 : 1)) void mlp_forward_kernel(FwdParams p) {
   using P = Prec<BF16>;
   using BPiece = typename P::BPiece;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
 
 // ---- pack kernel: nn.Linear tensors -> bias tiles + MFMA-A piece stream ---------------------------------
 
-template <bool BF16>
+template <int BF16>
 __global__ void pack_kernel(NetLayout L, PackPtrs ptrs, char* __restrict__ packed) {  // also used by mlp_train.hip
   using P = Prec<BF16>;
   const int KX = kXyzPanel, KD = round_up(3 + 6 * L.LD, 16);
@@ -407,12 +407,11 @@ __global__ void pack_kernel(NetLayout L, PackPtrs ptrs, char* __restrict__ packe
         }
       }
     }
-    if constexpr (BF16) reinterpret_cast<__bf16*>(wout)[idx] = static_cast<__bf16>(v);
-    else reinterpret_cast<float*>(wout)[idx] = v;
+    reinterpret_cast<typename P::Elem*>(wout)[idx] = static_cast<typename P::Elem>(v);
   }
 }
 
-template <int W, int LX, int LD, bool BF16, int PT, bool SAVE = false>
+template <int W, int LX, int LD, int BF16, int PT, bool SAVE = false>
 static int launch_forward(FwdParams p, hipStream_t stream) {
   auto kern = mlp_forward_kernel<W, LX, LD, BF16, PT, SAVE>;
   constexpr int WAVES = waves_of<BF16, PT>();
@@ -437,15 +436,23 @@ static int launch_forward(FwdParams p, hipStream_t stream) {
 
 int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStream_t stream) {
   const bool bf = precision == DN_PREC_BF16;
+  const bool hf = precision == DN_PREC_F16;
   // bf16 geometry: PT=1 (8 waves x 32 points, two waves per SIMD) measured fastest (1327 vs 1277 TFLOP/s for
   // PT=2 = 4 waves x 64 points, one wave per SIMD); DEXNERF_BF16_PT=2 selects the latter for experiments
   static const int bf16_pt = [] { const char* e = getenv("DEXNERF_BF16_PT"); return (e && atoi(e) == 2) ? 2 : 1; }();
+  if (p.act != nullptr && hf) { set_error("mlp_forward(train): fp16 is a render-only mode"); return DN_E_UNSUPPORTED; }
   if (p.act != nullptr) {  // training forward: LX=10 nets, PT=1
     if (d.num_encoding_fn_xyz == 10 && d.hidden_size == 256)
       return bf ? launch_forward<256, 10, 4, true, 1, true>(p, stream) : launch_forward<256, 10, 4, false, 1, true>(p, stream);
     if (d.num_encoding_fn_xyz == 10 && d.hidden_size == 128)
       return bf ? launch_forward<128, 10, 4, true, 1, true>(p, stream) : launch_forward<128, 10, 4, false, 1, true>(p, stream);
     set_error("mlp_forward(train): no kernel instance for W=%d L_xyz=%d", d.hidden_size, d.num_encoding_fn_xyz);
+    return DN_E_UNSUPPORTED;
+  }
+  if (hf) {  // fp16 render kernels: the L_xyz = 10 nets
+    if (d.num_encoding_fn_xyz == 10 && d.hidden_size == 256) return launch_forward<256, 10, 4, 2, 1>(p, stream);
+    if (d.num_encoding_fn_xyz == 10 && d.hidden_size == 128) return launch_forward<128, 10, 4, 2, 1>(p, stream);
+    set_error("mlp_forward(fp16): no kernel instance for W=%d L_xyz=%d", d.hidden_size, d.num_encoding_fn_xyz);
     return DN_E_UNSUPPORTED;
   }
 #define DN_CASE(W_, LX_)                                                                     \
@@ -483,9 +490,11 @@ int setup_params(const dn_mlp_desc* desc, int precision, const void* packed, Fwd
 
 int launch_pack(const NetLayout& L, const PackPtrs& ptrs, void* packed, int precision, hipStream_t stream) {
   if (precision == DN_PREC_BF16)
-    hipLaunchKernelGGL(pack_kernel<true>, dim3(512), dim3(256), 0, stream, L, ptrs, static_cast<char*>(packed));
+    hipLaunchKernelGGL(pack_kernel<1>, dim3(512), dim3(256), 0, stream, L, ptrs, static_cast<char*>(packed));
+  else if (precision == DN_PREC_F16)
+    hipLaunchKernelGGL(pack_kernel<2>, dim3(512), dim3(256), 0, stream, L, ptrs, static_cast<char*>(packed));
   else
-    hipLaunchKernelGGL(pack_kernel<false>, dim3(512), dim3(256), 0, stream, L, ptrs, static_cast<char*>(packed));
+    hipLaunchKernelGGL(pack_kernel<0>, dim3(512), dim3(256), 0, stream, L, ptrs, static_cast<char*>(packed));
   return check_launch("mlp_pack");
 }
 

@@ -74,7 +74,7 @@ struct NetLayout {
 
 // kpp = k-values per piece: 16 (bf16) or 8 (fp32).
 inline int build_layout(const dn_mlp_desc& d, int precision, NetLayout* out) {
-  const int kpp = (precision == DN_PREC_BF16) ? 16 : 8;
+  const int kpp = (precision != DN_PREC_F32) ? 16 : 8;
   const int W = d.hidden_size, D = d.num_layers;
   const int KX = kXyzPanel;
   const int KD = round_up(3 + 6 * d.num_encoding_fn_dir, 16);
@@ -133,7 +133,7 @@ struct TrainLayout {
 };
 
 inline void build_train_layout(const dn_mlp_desc& d, int precision, TrainLayout* t) {
-  const bool bf = precision == DN_PREC_BF16;
+  const bool bf = precision != DN_PREC_F32;
   t->kpp = bf ? 16 : 8; t->epp = bf ? 8 : 4; t->ppt = bf ? 2 : 4;
   const int W = d.hidden_size, D = d.num_layers;
   t->kxp = kXyzPanel / t->kpp;
@@ -161,7 +161,7 @@ inline void build_train_layout(const dn_mlp_desc& d, int precision, TrainLayout*
 //   fc_rgb^T, layers_dir.0^T (feat rows only), [fc_feat^T | fc_alpha^T], layers_xyz[D-2..0]^T (hidden rows only).
 // (no-viewdirs nets: fc_out^T, then the trunk.)  No bias tiles.
 inline int build_backward_layout(const dn_mlp_desc& d, int precision, NetLayout* out) {
-  const int kpp = (precision == DN_PREC_BF16) ? 16 : 8;
+  const int kpp = (precision != DN_PREC_F32) ? 16 : 8;
   const int W = d.hidden_size, D = d.num_layers;
   const int DX = 3 + 6 * d.num_encoding_fn_xyz, DD = 3 + 6 * d.num_encoding_fn_dir;
   NetLayout& L = *out;
@@ -203,7 +203,7 @@ inline int build_backward_layout(const dn_mlp_desc& d, int precision, NetLayout*
 
 inline int validate_desc(const dn_mlp_desc* d, int precision) {
   if (!d) { set_error("mlp: NULL descriptor"); return DN_E_INVAL; }
-  if (precision != DN_PREC_F32 && precision != DN_PREC_BF16) { set_error("mlp: unknown precision %d", precision); return DN_E_INVAL; }
+  if (precision != DN_PREC_F32 && precision != DN_PREC_BF16 && precision != DN_PREC_F16) { set_error("mlp: unknown precision %d", precision); return DN_E_INVAL; }
   const bool ok = (d->hidden_size == 128 || d->hidden_size == 256) && d->num_layers >= 2 && d->num_layers <= 32 &&
                   d->skip_connect_every >= 1 && d->include_input_xyz == 1 && (d->include_input_dir == 1 || !d->use_viewdirs) &&
                   (d->num_encoding_fn_xyz == 10 || d->num_encoding_fn_xyz == 6) &&

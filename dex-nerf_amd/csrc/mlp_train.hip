@@ -27,7 +27,7 @@ struct BwdParams {
   int gslot_dirout, gslot_feat, gslot_trunk0, gslot_layer1, gslot_out;
 };
 
-template <int W, bool BF16>
+template <int W, int BF16>
 __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void mlp_backward_kernel(BwdParams p) {
   using P = Prec<BF16>;
   using BPiece = typename P::BPiece;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
 
 // ---- native piece layout -> plain (P, width) fp32 rows -------------------------------------------------------
 // kind 0: hidden vector (feature = 32*(q/PPT) + acc_row(...)); kind 1/2: xyz / dir positional encoding.
-template <bool BF16>
+template <int BF16>
 __global__ void unpack_kernel(const char* __restrict__ native, int pieces_per_tile, int slot0, int n_pieces, int kind,
                               int L, long long n_points, float* __restrict__ out, int ld_out, int col0) {
   using P = Prec<BF16>;
@@ -205,7 +205,7 @@ __global__ void unpack_kernel(const char* __restrict__ native, int pieces_per_ti
   }
 }
 
-template <int W, bool BF16>
+template <int W, int BF16>
 static int launch_backward(BwdParams p, hipStream_t stream) {
   auto kern = mlp_backward_kernel<W, BF16>;
   constexpr int WAVES = waves_of<BF16, 1>();
@@ -225,7 +225,7 @@ static int launch_backward(BwdParams p, hipStream_t stream) {
 
 static long long padded_tiles(long long n_points, int precision) {
   // both training kernels process whole workgroup tiles; buffers are sized for the padded tile count
-  const int per_wg = 32 * (precision == DN_PREC_BF16 ? 8 : 4);
+  const int per_wg = 32 * (precision != DN_PREC_F32 ? 8 : 4);
   return (n_points + per_wg - 1) / per_wg * (per_wg / 32);
 }
 
@@ -237,6 +237,7 @@ extern "C" int dn_mlp_train_sizes(const dn_mlp_desc* desc, int precision, int64_
                                   size_t* mask_bytes, size_t* grad_bytes) {
   int rc = validate_desc(desc, precision);
   if (rc) return rc;
+  DN_REQUIRE(precision != DN_PREC_F16, "training kernels exist for fp32 and bf16 (fp16 is a render-only mode)");
   DN_REQUIRE(n_points >= 0 && act_bytes && mask_bytes && grad_bytes, "dn_mlp_train_sizes: bad arguments");
   DN_REQUIRE(desc->num_encoding_fn_xyz == 10, "dn_mlp_train_sizes: training kernels are built for L_xyz = 10");
   TrainLayout t;
@@ -308,6 +309,7 @@ extern "C" int dn_mlp_backward_data(const dn_mlp_desc* desc, int precision, cons
                                     const void* masks, int64_t n_points, void* grads, dn_stream_t stream) {
   int rc = validate_desc(desc, precision);
   if (rc) return rc;
+  DN_REQUIRE(precision != DN_PREC_F16, "dn_mlp_backward_data: fp16 is a render-only mode");
   DN_REQUIRE(packed_bwd && g_out && masks && grads && n_points >= 0, "dn_mlp_backward_data: bad arguments");
   DN_REQUIRE((reinterpret_cast<uintptr_t>(g_out) & 15) == 0, "dn_mlp_backward_data: g_out must be 16-byte aligned");
   if (n_points == 0) return 0;

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("DEXNERF_HIP_LIB", os.path.join(os.path.dirname(_HERE)
 
 PREC_F32 = 0
 PREC_BF16 = 1
+PREC_F16 = 2
 
 EXPORTS = (
     "dn_abi_version", "dn_last_error", "dn_ray_bundle", "dn_coarse_depths", "dn_positional_encoding",

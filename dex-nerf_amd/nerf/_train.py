@@ -17,7 +17,7 @@ def needs_grad(model, *tensors):
 
 
 def train_fused_ok(model):
-    return model.fused_ok() and model.num_encoding_fn_xyz == 10
+    return model.fused_ok() and model.num_encoding_fn_xyz == 10 and _ops._precision != _hip.PREC_F16
 
 
 def _slots(model, precision):

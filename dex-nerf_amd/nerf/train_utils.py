@@ -78,7 +78,7 @@ def run_network(network_fn, pts, ray_batch, chunksize, embed_fn, embeddirs_fn):
     HIP kernel (encoding never materialised); any other callable gets the generic composition:
     HIP encoding -> network_fn minibatches -> concat."""
     _require_device(pts, "run_network")
-    if _fusable(network_fn, embed_fn, embeddirs_fn) and (train_fused_ok(network_fn) or not needs_grad(network_fn, pts)):
+    if _fusable(network_fn, embed_fn, embeddirs_fn) and (train_fused_ok(network_fn) or not needs_grad(network_fn, pts)):  # noqa: E501
         s = pts.shape[-2] if pts.dim() >= 2 else 1
         viewdirs = ray_batch[..., -3:] if network_fn.use_viewdirs else None
         log_dir = embeddirs_fn.log_sampling if network_fn.use_viewdirs else True

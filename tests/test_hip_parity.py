@@ -253,15 +253,16 @@ def test_render_goldens_end_to_end(golden, dev, name, monkeypatch):
         assert len(out6) == 6  # m_thres_cand=None: exactly six outputs (eval_nerf.py:175-187)
 
 
-def test_bf16_mode_psnr(golden, dev):
-    """Throughput mode: bf16 MFMA with fp32 accumulation, judged on PSNR against the fp32 reference outputs."""
+@pytest.mark.parametrize("precision,psnr_min", [("bf16", 35.0), ("fp16", 48.0)])
+def test_16bit_modes_psnr(golden, dev, precision, psnr_min):
+    """Throughput modes: bf16 / fp16 MFMA with fp32 accumulation, judged on PSNR against the fp32 reference outputs."""
     import nerf
     name = "render_lego_val"
     g = golden(name)
     mkw, wfn, rkw = CASES[name]
     mc, mf = make_models(mkw, *wfn(), dev)
     ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
-    nerf.set_precision("bf16")
+    nerf.set_precision(precision)
     try:
         with torch.no_grad():
             out = nerf.run_one_iter_of_nerf(1, len(g["ro"]), 1.0, mc, mf, G(g["ro"], dev)[None], G(g["rd"], dev)[None],
@@ -271,8 +272,8 @@ def test_bf16_mode_psnr(golden, dev):
         nerf.set_precision("fp32")
     mse = float(np.mean((C(out[3]).reshape(-1, 3) - g["out_rgb_fine"]) ** 2))
     psnr = -10.0 * np.log10(max(mse, 1e-12))
-    print(f"bf16 vs reference rgb_fine PSNR {psnr:.1f} dB")
-    assert psnr > 35.0
+    print(f"{precision} vs reference rgb_fine PSNR {psnr:.1f} dB")
+    assert psnr > psnr_min
 
 
 def test_large_render_properties_and_oracle(dev):

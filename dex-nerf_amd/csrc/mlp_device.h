@@ -109,6 +109,11 @@ struct Pipe {
   const char* rd_nxt;
   unsigned lane16;
   f32x4 af[kPrefetch];  // A-fragment FIFO: af[pos % kPrefetch] holds piece `pos` when it is consumed
+#ifdef DN_EXP_REGSTAGE
+  f32x4 stage[PER_WAVE];
+  unsigned stage_dst;
+  bool have_stage = false;
+#endif
 
   // DMA of one phase = PER_WAVE consecutive pieces per wave, as ONE opaque asm statement: SGPR-base form of
   // global_load_lds (32-bit lane offset), M0 saved/restored inside the statement, and a wave-uniform skip
@@ -187,16 +192,35 @@ struct Pipe {
     if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
 #endif
+#ifdef DN_EXP_REGSTAGE
+    // experiment: weights through registers (global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA
+    if (have_stage) {
+#pragma unroll
+      for (int e = 0; e < PER_WAVE; ++e)
+        *reinterpret_cast<f32x4*>(ring + stage_dst + e * kPieceBytes + lane16) = stage[e];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    advance_issue();
+#pragma unroll
+    for (int e = 0; e < PER_WAVE; ++e)
+      stage[e] = *reinterpret_cast<const f32x4*>(wsrc + pend_src + e * kPieceBytes + lane16);
+    stage_dst = pend_dst;
+    have_stage = true;
+#else
     __builtin_amdgcn_s_barrier();
     advance_issue();
     dma_phase(pend_src, pend_dst, (WAVES == 4 || wave < 4) ? 1u : 0u);
+#endif
     rd_cur = rd_nxt;
     slot_nxt = (slot_nxt + 1 == kRingPhases) ? 0 : slot_nxt + 1;
     rd_nxt = ring + slot_nxt * kSlotBytes + lane16;
   }
 
   __device__ __forceinline__ void mid_phase() {
+#ifndef DN_EXP_REGSTAGE
     if constexpr (WAVES == 8) dma_phase(pend_src, pend_dst, wave >= 4 ? 1u : 0u);
+#endif
   }
 
   // Padding pieces (the stream is padded to whole phases): advance the FIFO over N pieces starting at position

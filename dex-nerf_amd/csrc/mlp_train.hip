@@ -364,27 +364,59 @@ extern "C" int dn_mlp_unpack(const dn_mlp_desc* desc, int precision, int which, 
 // The contraction runs over POINTS, which both saved tensors keep on the lane axis, so each 1 KiB native piece
 // (64 lanes x 8 features) is staged in LDS as is (LDS-DMA, lane-linear) and read back TRANSPOSED with
 // ds_read_b64_tr_b16: a 16-lane group fetches 4 points x 16 features and every lane receives one feature of those
-// 4 points - two reads build the 8-point MFMA fragment of one feature row.  One workgroup owns the whole
-// (N x K) gradient of a layer for a strided set of 32-point tiles (8 waves: one 32-row n-tile each, all k-tiles)
-// and adds its partial with fp32 atomics at the end (128-byte row segments).  An all-ones B tile yields db.
+// 4 points - two reads build the 8-point MFMA fragment of one feature row.  One workgroup (8 waves, one per CU:
+// the accumulators take the register file) owns the whole (N x K) gradient of a layer for a strided set of
+// 32-point tiles and adds its partial with fp32 atomics at the end.  An all-ones B tile yields db.
+// The layer shape is a template parameter: the tile loop is straight-line code (a runtime-shaped version spent
+// 5x the MFMA time in scalar branches), and the LDS not needed for two tile buffers is used for depth: up to 16
+// tile buffers, all but one in flight, with counted vmcnt waits.
 // HBM-bound: (N + K) x 2 B per point against 2 N K FLOP per point (146 FLOP/B at 256 x 320).
 // ==============================================================================================================
+#ifndef DN_WG_EPI
+#define DN_WG_EPI 0
+#endif
 namespace dn {
-
-constexpr int kWgMaxKTiles = 11;  // 8 hidden + 2 xyz-PE + 1 all-ones (bias) tile
 
 struct WgParams {
   const char* act;
   const char* grads;
   int act_pieces, grad_pieces;
   long long n_points;
-  int g_slot, n_tiles_n;          // dY pieces: g_slot .. g_slot + 2*n_tiles_n
-  int custom_rows;                // > 0: dY is ONE custom piece (element (half h, e) = output row 8h+e), rows < custom_rows real
-  int x_slot, x_tiles;            // hidden X pieces (2 per 32-feature tile), may be 0
-  int pe_slot, pe_tiles, pe_L;    // positional-encoding pieces appended to X
+  int g_slot;                     // dY pieces: g_slot .. (2 per 32-row tile, or ONE custom piece)
+  int custom_rows;                // custom dY piece: element (half h, e) = output row 8h+e, rows < custom_rows real
+  int x_slot;                     // hidden X pieces (2 per 32-feature tile)
+  int pe_slot, pe_L;              // positional-encoding pieces appended to X
   float* dW;
   int ldw, col_pe0;
   float* db;
+  int shape;                      // index into the instantiation table (wg_shape_index)
+};
+
+constexpr int kWgLdsBytes = 144 * 1024;
+
+constexpr int wg_stages_for(int pieces) {
+  int s = kWgLdsBytes / (pieces * kPieceBytes);
+  if (s > 16) s = 16;
+  const int per_wave = (pieces + 7) / 8;
+  while (s > 2 && (s - 2) * per_wave > 48) --s;  // counted-wait range
+  return s < 2 ? 2 : s;
+}
+
+// NTN: 32-row tiles of the output (dY) width; XT: 32-column tiles of the hidden input; PET: 32-column tiles of the
+// appended positional encoding; CUSTOM: dY is the single custom output-gradient piece (fc_rgb / fc_alpha / fc_out)
+template <int NTN_, int XT_, int PET_, bool CUSTOM_>
+struct WgShape {
+  static constexpr int NTN = NTN_, XT = XT_, PET = PET_;
+  static constexpr bool CUSTOM = CUSTOM_;
+  static constexpr int KT = XT + PET + 1;                  // k-tiles incl. the all-ones (bias) tile
+  static constexpr int KGROUPS = 8 / NTN;                  // waves sharing one n-tile split the k-tiles
+  static constexpr int J = (KT + KGROUPS - 1) / KGROUPS;   // k-tiles (accumulators) per wave
+  static constexpr int N_DY = CUSTOM ? 1 : 2 * NTN;
+  static constexpr int N_X = 2 * XT, N_PE = 2 * PET;
+  static constexpr int PIECES = N_DY + N_X + N_PE;         // 1 KiB pieces staged per 32-point tile
+  static constexpr int PER_WAVE = (PIECES + 7) / 8;        // DMAs per tile of the busiest wave
+  static constexpr int STAGES = wg_stages_for(PIECES);
+  static_assert(XT + PET >= 1 && NTN * KGROUPS == 8, "shape");
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -408,20 +440,26 @@ __device__ __forceinline__ int tr_feature(int i) {
   return acc_row(fs * 8 + (li & 7), li >> 3);
 }
 
-__global__ __launch_bounds__(512, 2) void weight_grad_kernel(WgParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt range");
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+}
+
+// One unit = one nn.Linear's (dW, db); workgroup `wg` of the `n_wg` that share the unit takes 32-point tiles
+// wg, wg + n_wg, ...
+template <class S>
+__device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int n_wg, char* smem) {
+  const long long tiles = (p.n_points + 31) / 32;
+  if (wg >= tiles) return;  // nothing to add (workgroup-uniform)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n_dy = p.custom_rows > 0 ? 1 : 2 * p.n_tiles_n, n_x = 2 * p.x_tiles, n_pe = 2 * p.pe_tiles;
-  const int n_pieces = n_dy + n_x + n_pe;
-  const int buf_bytes = n_pieces * kPieceBytes;
-  const long long tiles = (p.n_points + 31) / 32;
+  constexpr int BUF = S::PIECES * kPieceBytes;
 
   // wave -> (n-tile, subset of k-tiles)
-  const int ntile = wave % p.n_tiles_n;
-  const int kgroup = wave / p.n_tiles_n;
-  const int kgroups = 8 / p.n_tiles_n;
-  const int kt_total = p.x_tiles + p.pe_tiles + 1;  // + all-ones tile
+  const int ntile = wave % S::NTN;
+  const int kgroup = wave / S::NTN;
 
   // transposing read: lane (16-lane group g, li) supplies row (li>>2) / column chunk (li&3) of a 4 x 16 block and
   // receives feature column li; group g covers feature sub-block fs = g&1 and k-half hh = g>>1 of the MFMA operand
@@ -429,43 +467,86 @@ __global__ __launch_bounds__(512, 2) void weight_grad_kernel(WgParams p) {
   const int fs = grp & 1, hh = grp >> 1;
   const int lane_off = ((((li & 3) >> 1) * 32 + (li >> 2) + 8 * hh) * 16) + ((li & 3) & 1) * 8;
 
+  // ---- staging: each 1 KiB piece is one LDS-DMA (opaque asm: the counted waits below are ours; hipcc would drain
+  // with vmcnt(0) at every barrier).  This wave stages pieces wave, wave + 8, ... of every tile.
+  const unsigned lane16 = lane * 16;
+  const unsigned smem_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
+  const char* src0[S::PER_WAVE];
+  long long stride[S::PER_WAVE];
+  static_for<S::PER_WAVE>([&](auto e_c) {
+    constexpr int e = decltype(e_c)::value;
+    const int pi = wave + 8 * e;
+    if (pi < S::N_DY) { src0[e] = p.grads + static_cast<long long>(p.g_slot + pi) * kPieceBytes; stride[e] = static_cast<long long>(p.grad_pieces) * kPieceBytes; }
+    else if (pi < S::N_DY + S::N_X) { src0[e] = p.act + static_cast<long long>(p.x_slot + pi - S::N_DY) * kPieceBytes; stride[e] = static_cast<long long>(p.act_pieces) * kPieceBytes; }
+    else { src0[e] = p.act + static_cast<long long>(p.pe_slot + pi - S::N_DY - S::N_X) * kPieceBytes; stride[e] = static_cast<long long>(p.act_pieces) * kPieceBytes; }
+  });
   auto stage = [&](long long tile32, int buf) {
-    char* dst = smem + buf * buf_bytes;
-    for (int pi = wave; pi < n_pieces; pi += 8) {
-      const char* src;
-      if (pi < n_dy) src = p.grads + ((tile32 * p.grad_pieces + p.g_slot + pi) * 64 + lane) * 16;
-      else if (pi < n_dy + n_x) src = p.act + ((tile32 * p.act_pieces + p.x_slot + (pi - n_dy)) * 64 + lane) * 16;
-      else src = p.act + ((tile32 * p.act_pieces + p.pe_slot + (pi - n_dy - n_x)) * 64 + lane) * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dst + pi * kPieceBytes), 16, 0, 0);
-    }
+    if (tile32 >= tiles) tile32 = tiles - 1;  // past the end: harmless re-load, keeps the DMA count per stage constant
+    static_for<S::PER_WAVE>([&](auto e_c) {
+      constexpr int e = decltype(e_c)::value;
+      const unsigned long long src_bits = reinterpret_cast<unsigned long long>(src0[e] + tile32 * stride[e]);
+      const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(src_bits));
+      const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(src_bits >> 32));
+      const char* usrc = reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
+      const unsigned lds = __builtin_amdgcn_readfirstlane(smem_addr + buf * BUF + (wave + 8 * e) * kPieceBytes);
+      const unsigned go = __builtin_amdgcn_readfirstlane((wave + 8 * e < S::PIECES) ? 1u : 0u);
+      const unsigned voff = lane16;  // (asm operands do not capture: name a local)
+      unsigned keep;
+      asm volatile(
+          "s_cmp_lg_u32 %[go], 0\n\t"
+          "s_cbranch_scc0 .Ldn_wg_skip%=\n\t"
+          "s_mov_b32 %[keep], m0\n\t"
+          "s_mov_b32 m0, %[lds]\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %[voff], %[sbase]\n\t"
+          "s_mov_b32 m0, %[keep]\n"
+          ".Ldn_wg_skip%=:"
+          : [keep] "=&s"(keep)
+          : [go] "s"(go), [lds] "s"(lds), [voff] "v"(voff), [sbase] "s"(usrc)
+          : "memory", "scc");
+    });
+  };
+  // this wave issues PER_WAVE or PER_WAVE-1 DMAs per tile; STAGES-2 younger tiles may stay in flight (in-order retirement)
+  const bool full = (wave + 8 * (S::PER_WAVE - 1)) < S::PIECES;
+  auto wait_tile = [&]() {
+    if (full) wait_vmcnt<(S::STAGES - 2) * S::PER_WAVE>();
+    else wait_vmcnt<(S::STAGES - 2) * (S::PER_WAVE - 1)>();
   };
 
-  f32x16 acc[kWgMaxKTiles];
+  f32x16 acc[S::J];
 #pragma unroll
-  for (int k = 0; k < kWgMaxKTiles; ++k)
+  for (int k = 0; k < S::J; ++k)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
-  bf16x8 ones;
+  bf16x8 ones, zeros;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = static_cast<__bf16>(1.0f);
+  for (int e = 0; e < 8; ++e) { ones[e] = static_cast<__bf16>(1.0f); zeros[e] = static_cast<__bf16>(0.0f); }
 
-  long long tile = blockIdx.x;
+  long long tile = wg;
   int buf = 0;
-  if (tile < tiles) stage(tile, 0);
-  for (; tile < tiles; tile += gridDim.x) {
-    __syncthreads();  // (hipcc drains the LDS-DMA with vmcnt(0) first) this tile landed; previous tile fully consumed
-    const long long nxt = tile + gridDim.x;
-    if (nxt < tiles) stage(nxt, buf ^ 1);
-    const char* base = smem + buf * buf_bytes + lane_off;
+#pragma unroll 1
+  for (int st = 0; st + 1 < S::STAGES; ++st) stage(tile + static_cast<long long>(st) * n_wg, st);
+#pragma unroll 1
+  for (; tile < tiles; tile += n_wg) {
+    // this wave's DMAs of tile `tile` are done, and so are its LDS reads of the previous tile ...
+    wait_tile();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ... after the barrier everyone's are: the tile is resident and the previous tile's buffer is free
+    __builtin_amdgcn_s_barrier();
+    {
+      int nb = buf + S::STAGES - 1;
+      if (nb >= S::STAGES) nb -= S::STAGES;
+      stage(tile + static_cast<long long>(S::STAGES - 1) * n_wg, nb);
+    }
+    const char* base = smem + buf * BUF + lane_off;
     // A = dY^T fragments of this wave's n-tile, two 16-point k-steps
-    // (a custom dY has a single piece: the fs=1 lane groups re-read it and are zeroed below)
-    const int dy_piece = p.custom_rows > 0 ? 0 : 2 * ntile + fs;
+    // (a custom dY has a single piece: the fs=1 lane groups re-read it and are zeroed)
+    const int dy_piece = S::CUSTOM ? 0 : 2 * ntile + fs;
     bf16x8 a0 = tr_frag(base + dy_piece * kPieceBytes, 0);
     bf16x8 a1 = tr_frag(base + dy_piece * kPieceBytes, 16);
-    if (p.custom_rows > 0 && fs == 1) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { a0[e] = static_cast<__bf16>(0.0f); a1[e] = static_cast<__bf16>(0.0f); }
+    if constexpr (S::CUSTOM) {
+      a0 = fs ? zeros : a0;
+      a1 = fs ? zeros : a1;
     }
     const long long valid = p.n_points - tile * 32;  // points of this tile that exist (the rest are padding copies)
     if (valid < 32) {
@@ -475,90 +556,266 @@ __global__ __launch_bounds__(512, 2) void weight_grad_kernel(WgParams p) {
         if (16 + 8 * hh + e >= valid) a1[e] = static_cast<__bf16>(0.0f);
       }
     }
-    static_for<kWgMaxKTiles>([&](auto kt_c) {
-      constexpr int kt = decltype(kt_c)::value;
-      if (kt < kt_total && (kt % kgroups) == kgroup) {
-        bf16x8 b0 = ones, b1 = ones;
-        if (kt < kt_total - 1) {
-          const char* pb = base + (n_dy + 2 * kt + fs) * kPieceBytes;
+    static_for<S::J>([&](auto j_c) {
+      constexpr int j = decltype(j_c)::value;
+      bf16x8 b0, b1;
+      if constexpr (S::KGROUPS == 1) {
+        if constexpr (j == S::KT - 1) { b0 = ones; b1 = ones; }
+        else {
+#ifndef DN_WG_NOREAD
+          const char* pb = base + (S::N_DY + 2 * j) * kPieceBytes + fs * kPieceBytes;
           b0 = tr_frag(pb, 0);
           b1 = tr_frag(pb, 16);
+#else
+          b0 = ones; b1 = ones;
+#endif
         }
-        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[kt], 0, 0, 0);
-        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[kt], 0, 0, 0);
+      } else {
+        const int kt = kgroup + j * S::KGROUPS;           // wave-uniform; kt >= KT: an unused accumulator
+        const int ktr = kt < S::KT - 1 ? kt : S::KT - 2;  // a piece that exists
+        const char* pb = base + (S::N_DY + 2 * ktr) * kPieceBytes + fs * kPieceBytes;
+        b0 = tr_frag(pb, 0);
+        b1 = tr_frag(pb, 16);
+        const bool is_ones = kt >= S::KT - 1;
+        b0 = is_ones ? ones : b0;
+        b1 = is_ones ? ones : b1;
       }
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
     });
-    buf ^= 1;
+    buf = (buf + 1 == S::STAGES) ? 0 : buf + 1;
   }
+  wait_vmcnt<0>();  // the trailing re-loads
   // ---- add this workgroup's partial: D[i][j] sits in lane (j = lane&31, half = lane>>5), register r, i = acc_row(r, half)
-  const int j = lane & 31, half = lane >> 5;
-  static_for<kWgMaxKTiles>([&](auto kt_c) {
-    constexpr int kt = decltype(kt_c)::value;
-    if (kt < kt_total && (kt % kgroups) == kgroup) {
+  const int jl = lane & 31, half = lane >> 5;
+  static_for<S::J>([&](auto j_c) {
+    constexpr int j = decltype(j_c)::value;
+    const int kt = kgroup + j * S::KGROUPS;
+    if (kt < S::KT) {
       int col;
-      if (kt < p.x_tiles) col = 32 * kt + tr_feature(j);
-      else if (kt < kt_total - 1) {
-        const int pe_piece = 2 * (kt - p.x_tiles) + (j >> 4);
-        const int pc = pe_slot_col(p.pe_L, (j & 15) >> 3, pe_piece * 8 + (j & 7));
+      if (kt < S::XT) col = 32 * kt + tr_feature(jl);
+      else if (kt < S::KT - 1) {
+        const int pe_piece = 2 * (kt - S::XT) + (jl >> 4);
+        const int pc = pe_slot_col(p.pe_L, (jl & 15) >> 3, pe_piece * 8 + (jl & 7));
         col = pc >= 0 ? p.col_pe0 + pc : -1;
-      } else col = (j == 0) ? -2 : -1;  // all-ones tile: column 0 carries the bias gradient
+      } else col = (jl == 0) ? -2 : -1;  // all-ones tile: column 0 carries the bias gradient
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int irow = acc_row(r, half);
         int n = 32 * ntile + tr_feature(irow);
-        if (p.custom_rows > 0) {
+        if constexpr (S::CUSTOM) {
           n = (irow < 16) ? ((irow & 15) >> 3) * 8 + (irow & 7) : p.custom_rows;  // custom piece: row = 8h + e
           if (n >= p.custom_rows) continue;
         }
-        if (col >= 0) atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col, acc[kt][r]);
-        else if (col == -2 && p.db != nullptr) atomicAdd(p.db + n, acc[kt][r]);
+#if DN_WG_EPI == 1
+        if (col >= 0 && acc[j][r] == 1.2345f) p.dW[static_cast<long long>(n) * p.ldw + col] = 1.0f;
+#else
+        if (col >= 0) atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col, acc[j][r]);
+        else if (col == -2 && p.db != nullptr) atomicAdd(p.db + n, acc[j][r]);
+#endif
       }
     }
   });
 }
 
-}  // namespace dn
+// the instantiated layer shapes: W = 256 and W = 128 nets (L_xyz = 10: a 64-wide xyz panel = 2 tiles; L_dir: 1 tile)
+#define DN_WG_SHAPES(X)                                                                                        \
+  X(0, 8, 0, 2, false) X(1, 8, 8, 0, false) X(2, 8, 8, 2, false) X(3, 4, 8, 1, false) X(4, 1, 8, 0, true)     \
+  X(5, 1, 4, 0, true)  X(6, 4, 0, 2, false) X(7, 4, 4, 0, false) X(8, 4, 4, 2, false) X(9, 2, 4, 1, false)    \
+  X(10, 1, 2, 0, true)
 
-extern "C" int dn_mlp_weight_grad(const dn_mlp_desc* desc, int precision, const void* act, const void* grads,
-                                  int64_t n_points, int g_slot, int n_out, int x_slot, int x_width, int pe_kind,
-                                  float* dW, int ldw, float* db, dn_stream_t stream) {
+static int wg_shape_index(int ntn, int xt, int pet, bool custom) {
+#define X(id, a, b, c, d) if (ntn == a && xt == b && pet == c && custom == d) return id;
+  DN_WG_SHAPES(X)
+#undef X
+  return -1;
+}
+static int wg_shape_pieces(int shape) {
+#define X(id, a, b, c, d) if (shape == id) return WgShape<a, b, c, d>::PIECES;
+  DN_WG_SHAPES(X)
+#undef X
+  return 0;
+}
+static int wg_shape_lds(int shape) {
+#define X(id, a, b, c, d) if (shape == id) return WgShape<a, b, c, d>::STAGES * WgShape<a, b, c, d>::PIECES * kPieceBytes;
+  DN_WG_SHAPES(X)
+#undef X
+  return 0;
+}
+
+__device__ __forceinline__ void weight_grad_dispatch(const WgParams& p, int wg, int n_wg, char* smem) {
+  switch (p.shape) {  // workgroup-uniform
+#define X(id, a, b, c, d) case id: weight_grad_unit<WgShape<a, b, c, d>>(p, wg, n_wg, smem); break;
+    DN_WG_SHAPES(X)
+#undef X
+    default: break;
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void weight_grad_kernel(WgParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  weight_grad_dispatch(p, blockIdx.x, gridDim.x, smem);
+}
+
+// All linear layers of a network in ONE launch: the workgroups are divided among the units in proportion to the
+// bytes each unit streams, so a unit's gradient is the sum of a few dozen partials instead of one per workgroup of
+// a whole-chip launch (the fp32 atomics of the epilogue are expensive: ~1 lane-op per L2 channel per clock).
+constexpr int kWgMaxUnits = 20;
+struct WgBatch {
+  int n_units;
+  int wg_begin[kWgMaxUnits + 1];  // unit u owns workgroups [wg_begin[u], wg_begin[u+1])
+  WgParams u[kWgMaxUnits];
+};
+
+__global__ __launch_bounds__(512, 2) void weight_grad_batch_kernel(WgBatch b) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int u = 0;
+  while (u + 1 < b.n_units && static_cast<int>(blockIdx.x) >= b.wg_begin[u + 1]) ++u;
+  const WgParams p = b.u[u];  // by value: the fields live in SGPRs, not behind kernarg loads inside the tile loop
+  weight_grad_dispatch(p, static_cast<int>(blockIdx.x) - b.wg_begin[u], b.wg_begin[u + 1] - b.wg_begin[u], smem);
+}
+
+static int wg_fill(const dn_mlp_desc* desc, const TrainLayout& t, const void* act, const void* grads, int64_t n_points,
+                   int g_slot, int n_out, int x_slot, int x_width, int pe_kind, float* dW, int ldw, float* db, WgParams* out) {
   const int custom_rows = (n_out < 32) ? n_out : 0;  // fc_rgb (3) / fc_alpha (1) / fc_out (4): one custom dY piece
   if (custom_rows) n_out = 32;
-  int rc = validate_desc(desc, precision);
-  if (rc) return rc;
-  DN_REQUIRE(precision == DN_PREC_BF16, "dn_mlp_weight_grad: bf16 buffers only (fp32 mode forms dW with library GEMMs)");
-  DN_REQUIRE(act && grads && dW && n_points >= 0 && n_out % 32 == 0 && x_width % 32 == 0 && pe_kind >= 0 && pe_kind <= 2,
-             "dn_mlp_weight_grad: bad arguments");
-  if (n_points == 0) return 0;
-  TrainLayout t;
-  build_train_layout(*desc, precision, &t);
+  DN_REQUIRE(n_out % 32 == 0 && x_width % 32 == 0 && pe_kind >= 0 && pe_kind <= 2, "weight_grad: bad layer shape");
   WgParams p{};
   p.act = static_cast<const char*>(act);
   p.grads = static_cast<const char*>(grads);
   p.act_pieces = t.act_pieces; p.grad_pieces = t.grad_pieces;
   p.n_points = n_points;
-  p.g_slot = g_slot; p.n_tiles_n = n_out / 32; p.custom_rows = custom_rows;
-  p.x_slot = x_slot; p.x_tiles = x_width / 32;
+  p.g_slot = g_slot; p.custom_rows = custom_rows;
+  p.x_slot = x_slot;
   p.pe_slot = pe_kind == 1 ? t.slot_xyz : t.slot_dir;
-  p.pe_tiles = pe_kind == 0 ? 0 : (pe_kind == 1 ? t.kxp : t.kdp) / 2;
+  const int pe_tiles = pe_kind == 0 ? 0 : (pe_kind == 1 ? t.kxp : t.kdp) / 2;
   p.pe_L = pe_kind == 1 ? desc->num_encoding_fn_xyz : desc->num_encoding_fn_dir;
   p.dW = dW; p.ldw = ldw; p.col_pe0 = x_width; p.db = db;
-  DN_REQUIRE(p.n_tiles_n == 8 || p.n_tiles_n == 4 || p.n_tiles_n == 2 || p.n_tiles_n == 1,
-             "dn_mlp_weight_grad: n_out must be 256, 128, 64 or < 32 (custom output gradient)");
-  DN_REQUIRE(p.x_tiles + p.pe_tiles + 1 <= kWgMaxKTiles * (8 / p.n_tiles_n), "dn_mlp_weight_grad: too many input columns");
-  const int n_pieces = (custom_rows ? 1 : 2 * p.n_tiles_n) + 2 * (p.x_tiles + p.pe_tiles);
-  const size_t lds = static_cast<size_t>(2) * n_pieces * kPieceBytes;
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(weight_grad_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -static_cast<int>(e); }
-    attr_set = true;
+  p.shape = wg_shape_index(n_out / 32, x_width / 32, pe_tiles, custom_rows > 0);
+  if (p.shape < 0) {
+    set_error("weight_grad: no kernel instance for a %d x (%d + %d) layer%s", n_out, x_width, 32 * pe_tiles, custom_rows ? " (custom dY)" : "");
+    return DN_E_UNSUPPORTED;
   }
+  *out = p;
+  return 0;
+}
+
+template <class K>
+static int wg_attr(K kern) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -static_cast<int>(e); }
+  return 0;
+}
+
+static int device_cus() {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  return cus;
+}
+
+}  // namespace dn
+
+extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, const void* act, const void* grads,
+                                      int64_t n_points, float* const* h_dW, float* const* h_db, dn_stream_t stream) {
+  int rc = validate_desc(desc, precision);
+  if (rc) return rc;
+  DN_REQUIRE(precision == DN_PREC_BF16, "dn_mlp_weight_grad_all: bf16 buffers only (fp32 mode forms dW with library GEMMs)");
+  DN_REQUIRE(act && grads && h_dW && h_db && n_points >= 0, "dn_mlp_weight_grad_all: bad arguments");
+  DN_REQUIRE(desc->num_encoding_fn_xyz == 10, "dn_mlp_weight_grad_all: training kernels are built for L_xyz = 10");
+  if (n_points == 0) return 0;
+  TrainLayout t;
+  build_train_layout(*desc, precision, &t);
+  NetLayout L;
+  build_layout(*desc, precision, &L);
+  const int W = desc->hidden_size, D = desc->num_layers;
+  const int dim_xyz = 3 + 6 * desc->num_encoding_fn_xyz, dim_dir = 3 + 6 * desc->num_encoding_fn_dir;
+  const int n_units = D + (desc->use_viewdirs ? 4 : 1);
+  DN_REQUIRE(n_units <= kWgMaxUnits, "dn_mlp_weight_grad_all: too many layers (%d)", n_units);
+  for (int i = 0; i < n_units; ++i) DN_REQUIRE(h_dW[i] && h_db[i], "dn_mlp_weight_grad_all: gradient tensor %d is NULL", i);
+  WgBatch b{};
+  b.n_units = n_units;
+  // parameter order: layer1, layers_xyz[0..D-2], then layers_dir.0, fc_alpha, fc_rgb, fc_feat | fc_out (models.py:207-229)
+  int u = 0;
+  if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_layer1, W, 0, 0, 1, h_dW[u], dim_xyz, h_db[u], &b.u[u]))) return rc;
+  ++u;
+  int x_slot = t.slot_layer1;
+  for (int i = 0; i + 1 < D; ++i, ++u) {
+    const bool skip = (L.skip_mask >> i) & 1u;
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_trunk0 + i * t.kh, W, x_slot, W, skip ? 1 : 0, h_dW[u],
+                      W + (skip ? dim_xyz : 0), h_db[u], &b.u[u])))
+      return rc;
+    x_slot = t.slot_trunk0 + i * t.kh;
+  }
+  if (desc->use_viewdirs) {
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_dirout, W / 2, t.slot_feat, W, 2, h_dW[u], W + dim_dir, h_db[u], &b.u[u]))) return rc;
+    ++u;
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out + 1, 1, x_slot, W, 0, h_dW[u], W, h_db[u], &b.u[u]))) return rc;
+    ++u;
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out, 3, t.slot_dirout, W / 2, 0, h_dW[u], W / 2, h_db[u], &b.u[u]))) return rc;
+    ++u;
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_feat, W, x_slot, W, 0, h_dW[u], W, h_db[u], &b.u[u]))) return rc;
+    ++u;
+  } else {
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out, 4, x_slot, W, 0, h_dW[u], W, h_db[u], &b.u[u]))) return rc;
+    ++u;
+  }
+  // divide the workgroups (one per CU) among the units in proportion to the pieces each streams (largest remainder)
   const long long tiles = (n_points + 31) / 32;
-  const long long grid = tiles < 2 * cus ? tiles : 2 * cus;
-  hipLaunchKernelGGL(weight_grad_kernel, dim3(static_cast<unsigned>(grid)), dim3(512), lds, as_stream(stream), p);
+  int total_wg = device_cus();
+  if (total_wg < n_units) total_wg = n_units;
+  long long cost[kWgMaxUnits], cost_sum = 0;
+  for (int i = 0; i < n_units; ++i) {
+    cost[i] = wg_shape_pieces(b.u[i].shape);
+    cost_sum += cost[i];
+  }
+  int share[kWgMaxUnits], given = 0;
+  long long rem[kWgMaxUnits];
+  for (int i = 0; i < n_units; ++i) {
+    share[i] = static_cast<int>(cost[i] * total_wg / cost_sum);
+    rem[i] = cost[i] * total_wg % cost_sum;
+    if (share[i] < 1) { share[i] = 1; rem[i] = 0; }
+    given += share[i];
+  }
+  while (given < total_wg) {
+    int best = 0;
+    for (int i = 1; i < n_units; ++i) if (rem[i] > rem[best]) best = i;
+    ++share[best]; rem[best] = -1; ++given;
+  }
+  b.wg_begin[0] = 0;
+  for (int i = 0; i < n_units; ++i) {
+    if (share[i] > tiles) share[i] = static_cast<int>(tiles);  // idle workgroups would exit at once anyway
+    b.wg_begin[i + 1] = b.wg_begin[i] + share[i];
+  }
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    if ((rc = wg_attr(weight_grad_batch_kernel))) return rc;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(weight_grad_batch_kernel, dim3(static_cast<unsigned>(b.wg_begin[n_units])), dim3(512), kWgLdsBytes,
+                     as_stream(stream), b);
+  return check_launch("dn_mlp_weight_grad_all");
+}
+
+extern "C" int dn_mlp_weight_grad(const dn_mlp_desc* desc, int precision, const void* act, const void* grads,
+                                  int64_t n_points, int g_slot, int n_out, int x_slot, int x_width, int pe_kind,
+                                  float* dW, int ldw, float* db, dn_stream_t stream) {
+  int rc = validate_desc(desc, precision);
+  if (rc) return rc;
+  DN_REQUIRE(precision == DN_PREC_BF16, "dn_mlp_weight_grad: bf16 buffers only (fp32 mode forms dW with library GEMMs)");
+  DN_REQUIRE(act && grads && dW && n_points >= 0, "dn_mlp_weight_grad: bad arguments");
+  if (n_points == 0) return 0;
+  TrainLayout t;
+  build_train_layout(*desc, precision, &t);
+  WgParams p{};
+  if ((rc = wg_fill(desc, t, act, grads, n_points, g_slot, n_out, x_slot, x_width, pe_kind, dW, ldw, db, &p))) return rc;
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    if ((rc = wg_attr(weight_grad_kernel))) return rc;
+    attr_set = true;
+  }
+  const int cus = device_cus();
+  const long long tiles = (n_points + 31) / 32;
+  const long long grid = tiles < cus ? tiles : cus;
+  hipLaunchKernelGGL(weight_grad_kernel, dim3(static_cast<unsigned>(grid)), dim3(512), wg_shape_lds(p.shape), as_stream(stream), p);
   return check_launch("dn_mlp_weight_grad");
 }

@@ -22,7 +22,7 @@ EXPORTS = (
     "dn_mlp_packed_bytes", "dn_mlp_pack", "dn_run_network", "dn_mlp_forward_encoded", "dn_volume_render",
     "dn_volume_render_backward", "dn_sample_pdf", "dn_fine_depths", "dn_render_workspace_bytes", "dn_render_rays",
     "dn_mlp_train_sizes", "dn_mlp_backward_packed_bytes", "dn_mlp_pack_backward", "dn_run_network_train",
-    "dn_mlp_backward_data", "dn_mlp_unpack", "dn_mlp_weight_grad",
+    "dn_mlp_backward_data", "dn_mlp_unpack", "dn_mlp_weight_grad", "dn_mlp_weight_grad_all",
 )
 
 
@@ -69,6 +69,7 @@ def _declare(lib):
     lib.dn_mlp_unpack.argtypes = [POINTER(MlpDesc), c_int, c_int, vp, c_int64, c_int, c_int, c_int, fp, c_int, c_int, vp]
     lib.dn_mlp_weight_grad.argtypes = [POINTER(MlpDesc), c_int, vp, vp, c_int64, c_int, c_int, c_int, c_int, c_int, fp, c_int,
                                        fp, vp]
+    lib.dn_mlp_weight_grad_all.argtypes = [POINTER(MlpDesc), c_int, vp, vp, c_int64, POINTER(c_void_p), POINTER(c_void_p), vp]
     for name in EXPORTS:
         if name not in ("dn_last_error", "dn_mlp_packed_bytes", "dn_render_workspace_bytes",
                         "dn_mlp_backward_packed_bytes"):

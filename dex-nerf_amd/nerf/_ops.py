@@ -147,6 +147,24 @@ def mlp_weight_grad(packed, act, grads, n_points, g_slot, n_out, x_slot, x_width
                                    x_slot, x_width, pe_kind, ptr(d_w), d_w.shape[1], ptr(d_b), stream()), "dn_mlp_weight_grad")
 
 
+def mlp_weight_grad_all(packed, act, grads, n_points, shapes):
+    """bf16 buffers: every layer's (dW, db) in one launch.  `shapes` = [(out, in)] in linear_modules() order; returns
+    [(dW, db)] as views of ONE zero-filled fp32 buffer."""
+    dev = act.device
+    total = sum(o * i + o for o, i in shapes)
+    flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    out, off = [], 0
+    for o, i in shapes:
+        d_w = flat[off:off + o * i].view(o, i); off += o * i
+        d_b = flat[off:off + o]; off += o
+        out.append((d_w, d_b))
+    wp = (c_void_p * len(out))(*[w.data_ptr() for w, _ in out])
+    bp = (c_void_p * len(out))(*[b.data_ptr() for _, b in out])
+    check(lib().dn_mlp_weight_grad_all(ctypes.byref(packed.desc), packed.precision, ptr(act), ptr(grads), n_points, wp, bp,
+                                       stream()), "dn_mlp_weight_grad_all")
+    return out
+
+
 def run_network_pts(packed, pts, viewdirs, samples_per_ray):
     pts = f32c(pts).reshape(-1, 3)
     n_pts = pts.shape[0]

@@ -81,28 +81,12 @@ class FusedNetFn(torch.autograd.Function):
             results[mod] = (dy.t() @ x, dy.sum(0))
 
         if pk.precision == _hip.PREC_BF16:
-            # weight/bias gradients of the wide layers straight from the native buffers (MFMA kernel, fp32 atomics)
-            def native(mod, g_slot, n_out, x_slot, x_width, pe_kind):
-                d_w = torch.zeros_like(mod.weight, dtype=torch.float32)
-                d_b = torch.zeros_like(mod.bias, dtype=torch.float32)
-                _ops.mlp_weight_grad(pk, act, grads, n, g_slot, n_out, x_slot, x_width, pe_kind, d_w, d_b)
-                results[mod] = (d_w, d_b)
-
-            native(model.layer1, gslots["layer1"], w, 0, 0, 1)
-            x_slot = slots["layer1"]
-            for i, layer in enumerate(model.layers_xyz):
-                native(layer, gslots["trunk0"] + i * kh, w, x_slot, w, 1 if i in model.skip_layers else 0)
-                x_slot = slots["trunk0"] + i * kh
-            if model.use_viewdirs:
-                native(model.fc_feat, gslots["feat"], w, x_slot, w, 0)
-                native(model.fc_alpha, gslots["out"] + 1, 1, x_slot, w, 0)
-                native(model.layers_dir[0], gslots["dirout"], w // 2, slots["feat"], w, 2)
-                native(model.fc_rgb, gslots["out"], 3, slots["dirout"], w // 2, 0)
-            else:
-                native(model.fc_out, gslots["out"], 4, x_slot, w, 0)
+            # every layer's weight/bias gradient straight from the native buffers, one launch (MFMA kernel, fp32 atomics)
+            mods = model.linear_modules()
+            res = _ops.mlp_weight_grad_all(pk, act, grads, n, [tuple(m.weight.shape) for m in mods])
             flat = []
-            for m in model.linear_modules():
-                flat.extend(results[m])
+            for d_w, d_b in res:
+                flat.extend((d_w, d_b))
             return (None, None, None, None, None, None) + tuple(flat)
 
         pe_xyz = _ops.mlp_unpack(pk, 0, act, n, slots["xyz"], model.dim_xyz, 1, rows(model.dim_xyz))

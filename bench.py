@@ -106,7 +106,7 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8):
     cfg.nerf.train.radiance_field_noise_std = 0.2
     cfg.nerf.train.chunksize = n_rays
     params = list(models[0].parameters()) + list(models[1].parameters())
-    opt = torch.optim.Adam(params, lr=5e-4)
+    opt = torch.optim.Adam(params, lr=5e-4, fused=True)  # one multi-tensor kernel instead of seven
     ro_f, rd_f = ro.reshape(-1, 3), rd.reshape(-1, 3)
     target = torch.rand(H * W, 3, device=dev)
 

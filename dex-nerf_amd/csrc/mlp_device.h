@@ -188,6 +188,9 @@ struct Pipe {
 #ifdef DN_EXP_SHALLOW  // ablation: only one younger phase in flight
     if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+#elif defined(DN_EXP_LOOSEWAIT)  // timing experiment only (UNSAFE: lets 8 more VMEM ops stay outstanding)
+    if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
 #else
     if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");

@@ -174,12 +174,14 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
       return p.act + ((tile32 * p.act_pieces + slot) * 64 + lane) * 16;
     };
     auto save_pieces = [&](auto nt_c, int t, int slot0, const BPiece* pieces) {
+#ifndef DN_EXP_NOSAVE
       if constexpr (SAVE) {
         constexpr int nt = decltype(nt_c)::value;
 #pragma unroll
         for (int s2 = 0; s2 < P::PPT; ++s2)
           *reinterpret_cast<BPiece*>(act_ptr(t, slot0 + nt * P::PPT + s2)) = pieces[nt * P::PPT + s2];
       }
+#endif
     };
     unsigned maskw[PT][4];
     auto mask_clear = [&]() {

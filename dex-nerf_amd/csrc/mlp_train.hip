@@ -87,7 +87,9 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
         constexpr int s = decltype(s_c)::value;
         const BPiece piece = make_piece<BF16, false, s>(acc);
         bout[nt * P::PPT + s] = piece;
+#ifndef DN_EXP_NOSAVE
         *reinterpret_cast<BPiece*>(grad_base + static_cast<long long>(gslot + nt * P::PPT + s) * 1024) = piece;
+#endif
       });
     };
 
@@ -492,6 +494,9 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
       const unsigned go = __builtin_amdgcn_readfirstlane((wave + 8 * e < S::PIECES) ? 1u : 0u);
       const unsigned voff = lane16;  // (asm operands do not capture: name a local)
       unsigned keep;
+#ifdef DN_WG_NOSTAGE
+      asm volatile("" : [keep] "=s"(keep) : [go] "s"(go), [lds] "s"(lds), [voff] "v"(voff), [sbase] "s"(usrc) : "memory");
+#else
       asm volatile(
           "s_cmp_lg_u32 %[go], 0\n\t"
           "s_cbranch_scc0 .Ldn_wg_skip%=\n\t"
@@ -504,6 +509,7 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
           : [keep] "=&s"(keep)
           : [go] "s"(go), [lds] "s"(lds), [voff] "v"(voff), [sbase] "s"(usrc)
           : "memory", "scc");
+#endif
     });
   };
   // this wave issues PER_WAVE or PER_WAVE-1 DMAs per tile; STAGES-2 younger tiles may stay in flight (in-order retirement)

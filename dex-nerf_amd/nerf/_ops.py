@@ -108,16 +108,28 @@ def train_sizes(packed, n_points):
     return a.value, m.value, g.value
 
 
-def run_network_train(packed, pts, viewdirs, samples_per_ray):
-    """Training forward: raw radiance field + the opaque (act, masks) buffers the backward needs."""
-    pts = f32c(pts).reshape(-1, 3)
-    n_pts = pts.shape[0]
-    assert n_pts % samples_per_ray == 0
-    dev = pts.device
+def run_network_train(packed, pts, viewdirs, samples_per_ray, rays=None, z_vals=None):
+    """Training forward: raw radiance field + the opaque (act, masks) buffers the backward needs.  Either explicit
+    points (+ per-ray view directions) or packed ray rows + depths (the points are formed in the kernel)."""
+    if rays is not None:
+        rays, z_vals = f32c(rays), f32c(z_vals)
+        n_rays, samples_per_ray = z_vals.shape
+        n_pts = n_rays * samples_per_ray
+        dev = rays.device
+    else:
+        pts = f32c(pts).reshape(-1, 3)
+        n_pts = pts.shape[0]
+        assert n_pts % samples_per_ray == 0
+        dev = pts.device
     a_bytes, m_bytes, _ = train_sizes(packed, n_pts)
     out = torch.empty((n_pts, 4), dtype=torch.float32, device=dev)
     act = torch.empty(a_bytes, dtype=torch.uint8, device=dev)
     masks = torch.empty(m_bytes, dtype=torch.uint8, device=dev)
+    if rays is not None:
+        check(lib().dn_run_network_train(ctypes.byref(packed.desc), packed.precision, ptr(packed.buffer), None, None, ptr(rays),
+                                         rays.shape[1], ptr(z_vals), n_pts // samples_per_ray, samples_per_ray, ptr(out),
+                                         ptr(act), ptr(masks), stream()), "dn_run_network_train")
+        return out, act, masks
     vd = None if viewdirs is None else f32c(viewdirs).reshape(-1, 3)
     check(lib().dn_run_network_train(ctypes.byref(packed.desc), packed.precision, ptr(packed.buffer), ptr(pts), ptr(vd), None,
                                      0, None, n_pts // samples_per_ray, samples_per_ray, ptr(out), ptr(act), ptr(masks),

@@ -44,13 +44,17 @@ class FusedNetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, pts, viewdirs, samples_per_ray, log_xyz, log_dir, *params):
+        """`pts` (P,3) + `viewdirs` (N,3), or - when `samples_per_ray` is None - packed ray rows (N,11) + depths (N,S)."""
         pk = model.packed(log_xyz, log_dir)
         mods = model.linear_modules()
-        key = tuple((m.weight.data_ptr(), m.weight._version) for m in mods)
+        key = model.param_key()
         if pk.key_bwd != key:
             _ops.pack_backward(pk, [m.weight for m in mods])
             pk.key_bwd = key
-        out, act, masks = _ops.run_network_train(pk, pts, viewdirs, samples_per_ray)
+        if samples_per_ray is None:
+            out, act, masks = _ops.run_network_train(pk, None, None, None, rays=pts, z_vals=viewdirs)
+        else:
+            out, act, masks = _ops.run_network_train(pk, pts, viewdirs, samples_per_ray)
         ctx.model, ctx.pk = model, pk
         ctx.n_points = out.shape[0]
         ctx.save_for_backward(act, masks)
@@ -118,6 +122,18 @@ def mlp_encoded(model, x):
     if needs_grad(model, x):
         return model._forward_modules(x)
     return _ops.mlp_forward_encoded(model.packed(), x)
+
+
+def run_network_fused_rays(model, rays, z_vals, log_xyz=True, log_dir=True):
+    """run_network on packed ray rows (N, 8|11) + depths (N, S): the sample points ro + rd * z are formed inside the
+    kernel (reference train_utils.py:136,177 materialise them).  Returns (N, S, 4)."""
+    n, s = z_vals.shape
+    if needs_grad(model) and train_fused_ok(model):
+        params = []
+        for m in model.linear_modules():
+            params += [m.weight, m.bias]
+        return FusedNetFn.apply(model, rays, z_vals, None, log_xyz, log_dir, *params).reshape(n, s, 4)
+    return _ops.run_network_rays(model.packed(log_xyz, log_dir), rays, z_vals)
 
 
 def run_network_fused(model, pts, viewdirs, samples_per_ray, log_xyz=True, log_dir=True):

@@ -7,6 +7,30 @@ import torch
 from . import _ops
 
 
+_optimizer_steps = [0]   # bumped by a global optimizer post-step hook (see FlexibleNeRFModel.packed)
+
+
+def _count_optimizer_step(*_args, **_kwargs):
+    _optimizer_steps[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_post_step  # noqa: E402
+
+_register_post_step(_count_optimizer_step)
+
+
+_optimizer_steps = [0]   # bumped by a global optimizer post-step hook (see FlexibleNeRFModel.packed)
+
+
+def _count_optimizer_step(*_args, **_kwargs):
+    _optimizer_steps[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_post_step  # noqa: E402
+
+_register_post_step(_count_optimizer_step)
+
+
 class FlexibleNeRFModel(torch.nn.Module):
     """Drop-in for reference nerf/models.py:185-256.
 
@@ -56,6 +80,11 @@ class FlexibleNeRFModel(torch.nn.Module):
             mods += [self.fc_out]
         return mods
 
+    def param_key(self):
+        """Changes whenever the parameters may have (see packed())."""
+        return tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version)
+                     for m in self.linear_modules()) + (_optimizer_steps[0],)
+
     def desc_kwargs(self, log_sampling_xyz=True, log_sampling_dir=True):
         return dict(num_layers=self.num_layers, hidden_size=self.hidden_size,
                     skip_connect_every=self.skip_connect_every, num_encoding_fn_xyz=self.num_encoding_fn_xyz,
@@ -64,12 +93,15 @@ class FlexibleNeRFModel(torch.nn.Module):
                     log_sampling_xyz=log_sampling_xyz, log_sampling_dir=log_sampling_dir)
 
     def packed(self, log_sampling_xyz=True, log_sampling_dir=True):
-        """MFMA fragment stream for the current parameters (re-packed when any parameter changed)."""
+        """MFMA fragment stream for the current parameters (re-packed when any parameter changed).
+
+        "Changed" = a new storage, a bumped tensor version (every ordinary in-place op), or ANY optimizer step since the
+        last pack: fused optimizers (`Adam(fused=True)`) update parameters without bumping their versions."""
         mods = self.linear_modules()
         dev = mods[0].weight.device
         prec = _ops._precision
         slot = (prec, bool(log_sampling_xyz), bool(log_sampling_dir), dev)
-        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in mods)
+        key = self.param_key()
         pk = self._packed.get(slot)
         if pk is None:
             pk = _ops.PackedMLP(self.desc_kwargs(log_sampling_xyz, log_sampling_dir), dev, prec)

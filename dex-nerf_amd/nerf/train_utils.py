@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from . import _ops
-from ._train import needs_grad, run_network_fused, train_fused_ok
+from ._train import needs_grad, run_network_fused, run_network_fused_rays, train_fused_ok
 from .models import FlexibleNeRFModel
 from .nerf_helpers import Embedder, _require_device, get_minibatches, ndc_rays
 from .nerf_helpers import sample_pdf_2 as sample_pdf  # noqa: F401  (reference train_utils.py:6 alias)
@@ -158,8 +158,17 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mo
     rays = _ops.f32c(ray_batch)
     ro, rd = rays[..., :3], rays[..., 3:6]
     z_vals = _ops.coarse_depths(rays, nc, lindisp, rand(n, nc) if perturb else None)
-    pts = ro[..., None, :] + rd[..., None, :] * z_vals[..., :, None]
-    rf = run_network(model_coarse, pts, rays, opt.chunksize, encode_position_fn, encode_direction_fn)
+
+    def network(model, z):
+        if fused_models and (train_fused_ok(model) or not needs_grad(model)):
+            # ray rows + depths straight into the fused kernel (the points are formed there)
+            lx = encode_position_fn.log_sampling
+            ld = encode_direction_fn.log_sampling if use_viewdirs else True
+            return run_network_fused_rays(model, rays, z, lx, ld)
+        pts = ro[..., None, :] + rd[..., None, :] * z[..., :, None]
+        return run_network(model, pts, rays, opt.chunksize, encode_position_fn, encode_direction_fn)
+
+    rf = network(model_coarse, z_vals)
     coarse = volume_render_radiance_field(rf, z_vals, rd, radiance_field_noise_std=std, white_background=white,
                                           m_thres_cand=thres)
     rgb_c, acc_c, weights, depth_c = coarse[0], coarse[2], coarse[3], coarse[4]
@@ -167,8 +176,7 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mo
         return tuple([rgb_c, depth_c, acc_c, None, None, None] + list(coarse[5:]))
     u = rand(n, nf) if perturb else None
     z_fine = _ops.fine_depths(z_vals, weights.detach(), nf, u)
-    pts = ro[..., None, :] + rd[..., None, :] * z_fine[..., :, None]
-    rf = run_network(model_fine, pts, rays, opt.chunksize, encode_position_fn, encode_direction_fn)
+    rf = network(model_fine, z_fine)
     fine_out = volume_render_radiance_field(rf, z_fine, rd, radiance_field_noise_std=std, white_background=white,
                                             m_thres_cand=thres)
     return tuple([rgb_c, depth_c, acc_c, fine_out[0], fine_out[4], fine_out[2]] + list(fine_out[5:]))
@@ -205,7 +213,10 @@ def run_one_iter_of_nerf(height, width, focal_length, model_coarse, model_fine, 
                                           encode_position_fn=encode_position_fn,
                                           encode_direction_fn=encode_direction_fn, m_thres_cand=thres)
               for batch in get_minibatches(rays, chunksize=getattr(options.nerf, mode).chunksize)]
-    images = [torch.cat(col, dim=0) if col[0] is not None else None for col in zip(*chunks)]
+    if len(chunks) == 1:
+        images = list(chunks[0])   # a single chunk: nothing to concatenate (cat would copy every map)
+    else:
+        images = [torch.cat(col, dim=0) if col[0] is not None else None for col in zip(*chunks)]
     if mode == "validation":
         if not model_fine:
             # coarse-only: rgb, depth, acc, (None x3), dex...  -> reference returns the 3 maps + three Nones

@@ -125,7 +125,7 @@ def main(argv=None):
     parallel.broadcast_parameters(student)
     torch.manual_seed(args.seed + 1000 + rank)
     bucket = parallel.FlatGradBucket(student)
-    opt = torch.optim.Adam(bucket.params, lr=args.lr)
+    opt = torch.optim.Adam(bucket.params, lr=args.lr, fused=True)
     start = 0
     if args.load_checkpoint:
         ck = torch.load(args.load_checkpoint, map_location=dev)

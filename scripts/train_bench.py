@@ -15,7 +15,7 @@ for prec in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["bf16", "fp32"]):
     cfg.nerf.train.radiance_field_noise_std = 0.2
     cfg.nerf.train.chunksize = n_rays
     params = list(models[0].parameters()) + list(models[1].parameters())
-    opt = torch.optim.Adam(params, lr=5e-4)
+    opt = torch.optim.Adam(params, lr=5e-4, fused=(os.environ.get("ADAM_FUSED", "1") == "1"))
     ro_f, rd_f = ro.reshape(-1, 3), rd.reshape(-1, 3)
     target_img = torch.rand(bench.H * bench.W, 3, device=dev)
 

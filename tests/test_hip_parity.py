@@ -656,3 +656,83 @@ def test_eval_driver_loads_reference_format_checkpoints(golden, dev, tmp_path):
         assert torch.isfinite(res2["frames"][0][0]).all()
     finally:
         nerf.set_precision("fp32")
+
+
+def test_weight_grad_all_equals_per_layer_launches(dev):
+    """dn_mlp_weight_grad_all (every layer in one launch, workgroups shared out among the layers) must give the same
+    gradients as one dn_mlp_weight_grad launch per layer on the same saved buffers: identical products, only the
+    fp32 summation order of the partials differs (1e-5 relative); ragged point count so the padded tail is masked."""
+    import nerf
+    from nerf import _ops, _train, synthetic as syn
+    nerf.set_precision("bf16")
+    try:
+        for kw in (dict(num_layers=8, hidden_size=256, skip_connect_every=4), dict(num_layers=4, hidden_size=128, skip_connect_every=2),
+                   dict(num_layers=3, hidden_size=128, skip_connect_every=4, use_viewdirs=False)):
+            kw = dict(dict(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True), **kw)
+            m = nerf.models.FlexibleNeRFModel(**kw)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(5, **kw).items()})
+            m = m.to(dev)
+            n_rays, s = 37, 21   # 777 points: not a multiple of 32
+            pts = torch.randn(n_rays * s, 3, device=dev)
+            vd = torch.nn.functional.normalize(torch.randn(n_rays, 3, device=dev), dim=-1) if kw["use_viewdirs"] else None
+            pk = m.packed()
+            mods = m.linear_modules()
+            _ops.pack_backward(pk, [x.weight for x in mods])
+            out, act, masks = _ops.run_network_train(pk, pts, vd, s)
+            n = out.shape[0]
+            grads = _ops.mlp_backward_data(pk, torch.randn(n, 4, device=dev), masks, n)
+            res = _ops.mlp_weight_grad_all(pk, act, grads, n, [tuple(x.weight.shape) for x in mods])
+            slots, gslots, kh = _train._slots(m, pk.precision)
+            w = m.hidden_size
+            per_layer = {}
+
+            def one(mod, g_slot, n_out, x_slot, x_width, pe_kind):
+                d_w = torch.zeros_like(mod.weight); d_b = torch.zeros_like(mod.bias)
+                _ops.mlp_weight_grad(pk, act, grads, n, g_slot, n_out, x_slot, x_width, pe_kind, d_w, d_b)
+                per_layer[mod] = (d_w, d_b)
+
+            one(m.layer1, gslots["layer1"], w, 0, 0, 1)
+            x_slot = slots["layer1"]
+            for i, layer in enumerate(m.layers_xyz):
+                one(layer, gslots["trunk0"] + i * kh, w, x_slot, w, 1 if i in m.skip_layers else 0)
+                x_slot = slots["trunk0"] + i * kh
+            if m.use_viewdirs:
+                one(m.fc_feat, gslots["feat"], w, x_slot, w, 0)
+                one(m.fc_alpha, gslots["out"] + 1, 1, x_slot, w, 0)
+                one(m.layers_dir[0], gslots["dirout"], w // 2, slots["feat"], w, 2)
+                one(m.fc_rgb, gslots["out"], 3, slots["dirout"], w // 2, 0)
+            else:
+                one(m.fc_out, gslots["out"], 4, x_slot, w, 0)
+            for mod, (d_w, d_b) in zip(mods, res):
+                ref_w, ref_b = per_layer[mod]
+                assert d_w.shape == mod.weight.shape and torch.isfinite(d_w).all()
+                assert rel_err(C(d_w), C(ref_w)) < 1e-5 and rel_err(C(d_b), C(ref_b)) < 1e-5
+                assert float(ref_w.abs().max()) > 0
+    finally:
+        nerf.set_precision("fp32")
+
+
+def test_fused_optimizer_step_reaches_the_kernels(dev):
+    """Adam(fused=True) changes the parameters without bumping tensor versions; the next render must run on the new
+    weights (the packed stream is rebuilt after any optimizer step)."""
+    import nerf
+    from nerf import _ops, synthetic as syn
+    kw = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+    m = nerf.models.FlexibleNeRFModel(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(9, **kw).items()})
+    m = m.to(dev)
+    pts = torch.randn(64 * 8, 3, device=dev)
+    vd = torch.nn.functional.normalize(torch.randn(64, 3, device=dev), dim=-1)
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    emb = torch.cat([ex(pts), ed(vd[:, None, :].expand(64, 8, 3).reshape(-1, 3))], -1)
+    with torch.no_grad():
+        before = _ops.run_network_pts(m.packed(), pts, vd, 8)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2, fused=True)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    with torch.no_grad():
+        after = _ops.run_network_pts(m.packed(), pts, vd, 8)
+        ref = m._forward_modules(emb)
+    assert not torch.allclose(before, after)
+    assert rel_err(C(after), C(ref)) < TOL

@@ -139,3 +139,23 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 text = open(os.path.join(root, f)).read()
                 assert "oracle" not in text.replace("no oracle in the fork", ""), os.path.join(root, f)
+
+
+def test_param_key_tracks_fused_optimizer_steps():
+    """Adam(fused=True) updates parameters without bumping tensor versions; the packed-weights cache key must still
+    change, or the HIP kernels would keep running on stale weights."""
+    import nerf
+    m = nerf.models.FlexibleNeRFModel()
+    k0 = m.param_key()
+    assert m.param_key() == k0
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    versions = [p._version for p in m.parameters()]
+    opt.step()
+    assert m.param_key() != k0
+    k1 = m.param_key()
+    with torch.no_grad():
+        m.layer1.weight.mul_(2.0)   # ordinary in-place op: version bump
+    assert m.param_key() != k1
+    del versions

@@ -107,14 +107,16 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8):
     cfg.nerf.train.chunksize = n_rays
     params = list(models[0].parameters()) + list(models[1].parameters())
     opt = torch.optim.Adam(params, lr=5e-4, fused=True)  # one multi-tensor kernel instead of seven
-    ro_f, rd_f = ro.reshape(-1, 3), rd.reshape(-1, 3)
-    target = torch.rand(H * W, 3, device=dev)
+    from nerf import synthetic as syn
+    image = torch.rand(H, W, 3, device=dev)
+    selector = nerf.RaySelector(H, W, torch.from_numpy(syn.scene_pose(7)), torch.from_numpy(syn.intrinsic(H, W)), 2.0, 6.0, device=dev)
 
     def step():
-        sel = torch.randint(0, H * W, (n_rays,), device=dev)
-        out = nerf.run_one_iter_of_nerf(H, W, 1.0, models[0], models[1], ro_f[sel], rd_f[sel], cfg, mode="train",
-                                        encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=M_THRES)
-        loss = nerf.img2mse(out[0], target[sel]) + nerf.img2mse(out[3], target[sel])
+        # pixel draw -> packed ray rows + target pixels in one kernel, then the reference's per-chunk entry point
+        rays, target = selector.select(selector.random_pixels(n_rays), image)
+        out = nerf.predict_and_render_radiance(rays, models[0], models[1], cfg, mode="train", encode_position_fn=ex,
+                                               encode_direction_fn=ed, m_thres_cand=M_THRES)
+        loss = nerf.img2mse(out[0], target) + nerf.img2mse(out[3], target)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
@@ -127,7 +129,7 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"rays_per_s": n_rays / dt, "ms_per_step": dt * 1e3, "rays_per_step": n_rays,
-            "what": "fwd+bwd+Adam, 64+128 samples, perturb + noise 0.2, D8/W256 x2, fused HIP training kernels"}
+            "what": "ray selection + fwd + bwd + fused Adam, 64+128 samples, perturb + noise 0.2, D8/W256 x2, fused HIP training kernels"}
 
 
 def cpu_baseline(sample_rays=16384):

@@ -178,8 +178,19 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
       if constexpr (SAVE) {
         constexpr int nt = decltype(nt_c)::value;
 #pragma unroll
-        for (int s2 = 0; s2 < P::PPT; ++s2)
-          *reinterpret_cast<BPiece*>(act_ptr(t, slot0 + nt * P::PPT + s2)) = pieces[nt * P::PPT + s2];
+        for (int s2 = 0; s2 < P::PPT; ++s2) {
+          char* dst = act_ptr(t, slot0 + nt * P::PPT + s2);
+          const BPiece val = pieces[nt * P::PPT + s2];
+#if defined(DN_EXP_STORE) && DN_EXP_STORE == 1
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(val) : "memory");
+#elif defined(DN_EXP_STORE) && DN_EXP_STORE == 2
+          asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(val) : "memory");
+#elif defined(DN_EXP_STORE) && DN_EXP_STORE == 3
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(val) : "memory");
+#else
+          *reinterpret_cast<BPiece*>(dst) = val;
+#endif
+        }
       }
 #endif
     };

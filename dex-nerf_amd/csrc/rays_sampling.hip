@@ -36,6 +36,66 @@ __global__ void ray_bundle_kernel(RayBundleArgs a, float* __restrict__ ro, float
   }
 }
 
+// Training-ray selection (reference train_dexnerf_rgb.py:229-242 + the packing of train_utils.py:225-250): for each
+// chosen pixel build the packed ray row [ro3, rd3, near, far, viewdir3] directly (same arithmetic as
+// ray_bundle_kernel for rd; viewdir = rd / ||rd||, train_utils.py:225) and gather the target pixel's RGB.
+__global__ void select_rays_kernel(RayBundleArgs a, float near, float far, const int64_t* __restrict__ pix, int64_t n,
+                                   const float* __restrict__ image, int channels, float* __restrict__ rays,
+                                   float* __restrict__ target) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t px = pix[i];
+  const int row = static_cast<int>(px / a.width);
+  const int col = static_cast<int>(px - static_cast<int64_t>(row) * a.width);
+  const float d0 = (static_cast<float>(col) - a.cx) / a.fx;
+  const float d1 = (static_cast<float>(row) - a.cy) / a.fx;
+  const float d2 = 1.0f;
+  float rd[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float p0 = d0 * a.rinv[3 * j + 0];
+    const float p1 = d1 * a.rinv[3 * j + 1];
+    const float p2 = d2 * a.rinv[3 * j + 2];
+    rd[j] = (p0 + p1) + p2;
+  }
+  const float nrm = sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);
+  float* r = rays + i * 11;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    r[j] = a.origin[j];
+    r[3 + j] = rd[j];
+    r[8 + j] = rd[j] / nrm;
+  }
+  r[6] = near;
+  r[7] = far;
+  if (target != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) target[i * 3 + c] = image[px * channels + c];
+  }
+}
+
+// Forward-facing NDC warp (reference nerf/nerf_helpers.py:172-199), op for op (compiled -ffp-contract=off).
+__global__ void ndc_rays_kernel(double h, double w, double focal, double near_d, const float* __restrict__ ro,
+                                const float* __restrict__ rd, int64_t n, float* __restrict__ ro_out,
+                                float* __restrict__ rd_out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float dx = rd[i * 3 + 0], dy = rd[i * 3 + 1], dz = rd[i * 3 + 2];
+  const float near = static_cast<float>(near_d);
+  const float t = -(near + ro[i * 3 + 2]) / dz;
+  const float ox = ro[i * 3 + 0] + t * dx, oy = ro[i * 3 + 1] + t * dy, oz = ro[i * 3 + 2] + t * dz;
+  // python-float constants are computed in double and then meet fp32 tensors as fp32 scalars
+  const float cw = static_cast<float>(-1.0 / (w / (2.0 * focal)));
+  const float ch = static_cast<float>(-1.0 / (h / (2.0 * focal)));
+  const float two_near = static_cast<float>(2.0 * near_d);
+  ro_out[i * 3 + 0] = cw * ox / oz;
+  ro_out[i * 3 + 1] = ch * oy / oz;
+  ro_out[i * 3 + 2] = 1.0f + two_near / oz;
+  rd_out[i * 3 + 0] = cw * (dx / dz - ox / oz);
+  rd_out[i * 3 + 1] = ch * (dy / dz - oy / oz);
+  rd_out[i * 3 + 2] = -two_near / oz;
+}
+
 // ------------------------------------------------------------------------------------------------
 // S3 coarse depths (reference nerf/train_utils.py:111-133)
 // ------------------------------------------------------------------------------------------------
@@ -278,6 +338,35 @@ extern "C" int dn_ray_bundle(int height, int width, const float* h_rinv9, const 
   const unsigned grid = static_cast<unsigned>((total + block - 1) / block);
   hipLaunchKernelGGL(ray_bundle_kernel, dim3(grid), dim3(block), 0, as_stream(stream), a, ro, rd);
   return check_launch("dn_ray_bundle");
+}
+
+extern "C" int dn_select_rays(int height, int width, const float* h_rinv9, const float* h_origin3, float fx, float cx,
+                              float cy, float near, float far, const int64_t* pixel_index, int64_t n_rays,
+                              const float* image, int channels, float* rays, float* target, dn_stream_t stream) {
+  if (n_rays == 0) return 0;
+  DN_REQUIRE(height > 0 && width > 0 && h_rinv9 && h_origin3 && pixel_index && rays && n_rays >= 0,
+             "dn_select_rays: bad arguments");
+  DN_REQUIRE(target == nullptr || (image != nullptr && channels >= 3), "dn_select_rays: target requested without an image of >= 3 channels");
+  RayBundleArgs a;
+  for (int i = 0; i < 9; ++i) a.rinv[i] = h_rinv9[i];
+  for (int i = 0; i < 3; ++i) a.origin[i] = h_origin3[i];
+  a.fx = fx; a.cx = cx; a.cy = cy; a.height = height; a.width = width;
+  const int block = 256;
+  const unsigned grid = static_cast<unsigned>((n_rays + block - 1) / block);
+  hipLaunchKernelGGL(select_rays_kernel, dim3(grid), dim3(block), 0, as_stream(stream), a, near, far, pixel_index, n_rays,
+                     image, channels, rays, target);
+  return check_launch("dn_select_rays");
+}
+
+extern "C" int dn_ndc_rays(int height, int width, double focal, double near, const float* rays_o, const float* rays_d,
+                           int64_t n_rays, float* rays_o_out, float* rays_d_out, dn_stream_t stream) {
+  if (n_rays == 0) return 0;
+  DN_REQUIRE(rays_o && rays_d && rays_o_out && rays_d_out && n_rays >= 0 && height > 0 && width > 0, "dn_ndc_rays: bad arguments");
+  const int block = 256;
+  const unsigned grid = static_cast<unsigned>((n_rays + block - 1) / block);
+  hipLaunchKernelGGL(ndc_rays_kernel, dim3(grid), dim3(block), 0, as_stream(stream), static_cast<double>(height),
+                     static_cast<double>(width), focal, near, rays_o, rays_d, n_rays, rays_o_out, rays_d_out);
+  return check_launch("dn_ndc_rays");
 }
 
 extern "C" int dn_coarse_depths(const float* rays, int ray_stride, int64_t n_rays, int num_coarse, int lindisp,

@@ -23,6 +23,7 @@ EXPORTS = (
     "dn_volume_render_backward", "dn_sample_pdf", "dn_fine_depths", "dn_render_workspace_bytes", "dn_render_rays",
     "dn_mlp_train_sizes", "dn_mlp_backward_packed_bytes", "dn_mlp_pack_backward", "dn_run_network_train",
     "dn_mlp_backward_data", "dn_mlp_unpack", "dn_mlp_weight_grad", "dn_mlp_weight_grad_all",
+    "dn_select_rays", "dn_ndc_rays", "dn_dex_error_sweep", "dn_depth_error_image",
 )
 
 
@@ -69,6 +70,11 @@ def _declare(lib):
     lib.dn_mlp_unpack.argtypes = [POINTER(MlpDesc), c_int, c_int, vp, c_int64, c_int, c_int, c_int, fp, c_int, c_int, vp]
     lib.dn_mlp_weight_grad.argtypes = [POINTER(MlpDesc), c_int, vp, vp, c_int64, c_int, c_int, c_int, c_int, c_int, fp, c_int,
                                        fp, vp]
+    lib.dn_select_rays.argtypes = [c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float, c_float, c_float, c_float,
+                                   vp, c_int64, fp, c_int, fp, fp, vp]
+    lib.dn_ndc_rays.argtypes = [c_int, c_int, ctypes.c_double, ctypes.c_double, fp, fp, c_int64, fp, fp, vp]
+    lib.dn_dex_error_sweep.argtypes = [fp, fp, c_int, c_int64, vp, c_float, c_float, vp, vp]
+    lib.dn_depth_error_image.argtypes = [fp, fp, vp, c_int, c_int, c_float, fp, vp]
     lib.dn_mlp_weight_grad_all.argtypes = [POINTER(MlpDesc), c_int, vp, vp, c_int64, POINTER(c_void_p), POINTER(c_void_p), vp]
     for name in EXPORTS:
         if name not in ("dn_last_error", "dn_mlp_packed_bytes", "dn_render_workspace_bytes",

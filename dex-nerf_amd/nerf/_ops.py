@@ -42,6 +42,52 @@ def ray_bundle(height, width, rinv, origin, fx, cx, cy, device):
     return ro, rd
 
 
+def select_rays(height, width, rinv, origin, fx, cx, cy, near, far, pixel_index, image=None):
+    """Packed ray rows (N,11) [ro, rd, near, far, viewdir] for the chosen pixels (+ their RGB from `image` (H,W,C))."""
+    pix = pixel_index.contiguous()
+    assert pix.dtype == torch.int64 and pix.is_cuda
+    n = pix.numel()
+    rays = torch.empty((n, 11), dtype=torch.float32, device=pix.device)
+    target, img, channels = None, None, 0
+    if image is not None:
+        img = f32c(image)
+        channels = img.shape[-1]
+        target = torch.empty((n, 3), dtype=torch.float32, device=pix.device)
+    check(lib().dn_select_rays(height, width, host_floats(rinv), host_floats(origin), float(fx), float(cx), float(cy), float(near),
+                               float(far), ptr(pix), n, ptr(img), channels, ptr(rays), ptr(target), stream()), "dn_select_rays")
+    return rays, target
+
+
+def ndc_rays(height, width, focal, near, rays_o, rays_d):
+    ro, rd = f32c(rays_o), f32c(rays_d)
+    n = ro.numel() // 3
+    ro_out, rd_out = torch.empty_like(ro), torch.empty_like(rd)
+    check(lib().dn_ndc_rays(int(height), int(width), float(focal), float(near), ptr(ro), ptr(rd), n, ptr(ro_out), ptr(rd_out),
+                            stream()), "dn_ndc_rays")
+    return ro_out, rd_out
+
+
+def dex_error_sweep(depth_gt, depth_pred, mask=None, gt_lo=0.0, gt_hi=1.25):
+    """(K,5) float64 device tensor of [sum |err| mm, #>2mm, #>4mm, #>8mm, #masked] per candidate map."""
+    gt = f32c(depth_gt).reshape(-1)
+    pred = f32c(depth_pred).reshape(-1, gt.numel())
+    k = pred.shape[0]
+    m = None if mask is None else mask.reshape(-1).to(torch.uint8).contiguous()
+    out = torch.empty((k, 5), dtype=torch.float64, device=gt.device)
+    check(lib().dn_dex_error_sweep(ptr(gt), ptr(pred), k, gt.numel(), ptr(m), float(gt_lo), float(gt_hi), ptr(out), stream()),
+          "dn_dex_error_sweep")
+    return out
+
+
+def depth_error_image(depth_est, depth_gt, mask, abs_thres=1.0):
+    est, gt = f32c(depth_est), f32c(depth_gt)
+    h, w = gt.shape[-2:]
+    m = mask.to(torch.uint8).contiguous()
+    out = torch.empty((h, w, 3), dtype=torch.float32, device=gt.device)
+    check(lib().dn_depth_error_image(ptr(est), ptr(gt), ptr(m), h, w, float(abs_thres), ptr(out), stream()), "dn_depth_error_image")
+    return out
+
+
 def coarse_depths(rays, num_coarse, lindisp, t_rand=None):
     rays = f32c(rays)
     n = rays.shape[0]

@@ -107,13 +107,51 @@ class Embedder:
         return positional_encoding(x, self.num_encoding_functions, self.include_input, self.log_sampling)
 
 
+class RaySelector:
+    """Training-ray selection on the device (reference train_dexnerf_rgb.py:229-242 builds the
+    full-image bundle, a coordinate grid and three gathers per step, then run_one_iter_of_nerf normalises and packs).
+
+    One camera = one object: the two matrix inverses are taken once on the host (like get_ray_bundle), every
+    `select` is a single kernel that writes the packed (N,11) ray rows [ro, rd, near, far, viewdir] and the target
+    pixels.  `pixel_index` is a device int64 tensor of row-major indices h*W + w; `from_reference_choice` converts
+    the reference's `np.random.choice(H*W)` draws (its coordinate grid enumerates pixels column-major: f = w*H + h).
+    """
+
+    def __init__(self, height, width, extrinsic, intrinsic, near, far, device=None):
+        host = extrinsic.detach().to("cpu", torch.float32)
+        k = intrinsic.detach().to("cpu", torch.float32)
+        self.height, self.width = int(height), int(width)
+        self.rinv = torch.inverse(host[:3, :3]).reshape(-1).tolist()
+        self.origin = torch.inverse(host)[:3, -1].tolist()
+        self.fx, self.cx, self.cy = float(k[0, 0]), float(k[0, 2]), float(k[1, 2])
+        self.near, self.far = float(near), float(far)
+        self.device = torch.device(device) if device is not None else extrinsic.device
+
+    def from_reference_choice(self, select_inds):
+        f = torch.as_tensor(select_inds, dtype=torch.int64)
+        return ((f % self.height) * self.width + f // self.height).to(self.device)
+
+    def random_pixels(self, n, generator=None):
+        """n distinct pixels, drawn on the device (no host round trip)."""
+        total = self.height * self.width
+        return torch.randperm(total, device=self.device, generator=generator)[:min(n, total)]
+
+    def select(self, pixel_index, image=None):
+        return _ops.select_rays(self.height, self.width, self.rinv, self.origin, self.fx, self.cx, self.cy, self.near, self.far,
+                                pixel_index, image)
+
+
 def get_embedding_function(num_encoding_functions=6, include_input=True, log_sampling=True):
     """Reference nerf_helpers.py:162-169."""
     return Embedder(num_encoding_functions, include_input, log_sampling)
 
 
 def ndc_rays(H, W, focal, near, rays_o, rays_d):
-    """Forward-facing NDC warp (reference nerf_helpers.py:172-199); elementwise torch ops on any device."""
+    """Forward-facing NDC warp (reference nerf_helpers.py:172-199): one HIP kernel for device rays, the reference's
+    elementwise composition for host tensors."""
+    if rays_o.is_cuda and not (rays_o.requires_grad or rays_d.requires_grad):
+        o, d = _ops.ndc_rays(H, W, float(focal), float(near), rays_o.reshape(-1, 3), rays_d.reshape(-1, 3))
+        return o.reshape(rays_o.shape), d.reshape(rays_d.shape)
     t = -(near + rays_o[..., 2]) / rays_d[..., 2]
     rays_o = rays_o + t[..., None] * rays_d
     o0 = -1.0 / (W / (2.0 * focal)) * rays_o[..., 0] / rays_o[..., 2]

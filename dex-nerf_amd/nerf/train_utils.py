@@ -12,9 +12,18 @@ from .volume_rendering_utils import _thresholds, volume_render_radiance_field
 
 
 # ---- Dex depth metrics (reference train_utils.py:9-70; validation-time logging, numpy/torch host code) ----
+def _err_dict(row):
+    n = row[4]
+    return {"depth_abs_err": row[0] / n, "depth_err2": row[1] / n, "depth_err4": row[2] / n, "depth_err8": row[3] / n}
+
+
 def compute_err_metric(depth_gt, depth_pred, mask):
     """Masked depth errors (reference :9-30): mean |err| in millimetres (inputs are metres) and the fraction
-    of masked pixels whose error exceeds 2 / 4 / 8 mm.  `mask` is a boolean selector."""
+    of masked pixels whose error exceeds 2 / 4 / 8 mm.  `mask` is a boolean selector.  Device inputs are reduced by
+    one HIP kernel and a single 40-byte copy; host inputs by the reference's torch composition."""
+    if depth_gt.is_cuda:
+        out = _ops.dex_error_sweep(depth_gt, depth_pred.reshape(1, -1), mask.to(depth_gt.device))
+        return _err_dict(out[0].tolist())
     gt, pred = depth_gt[mask], depth_pred[mask]
     diff = torch.abs(gt - pred)
     count = diff.numel()
@@ -22,6 +31,22 @@ def compute_err_metric(depth_gt, depth_pred, mask):
             "depth_err2": int((diff > 2e-3).sum()) / count,
             "depth_err4": int((diff > 4e-3).sum()) / count,
             "depth_err8": int((diff > 8e-3).sum()) / count}
+
+
+def dex_error_sweep(depth_gt, depth_fine_dex, mask=None, gt_lo=0.0, gt_hi=1.25):
+    """The reference's validation loop over the Dex threshold candidates (train_dexnerf_rgb.py:391-408) on the device:
+    every candidate depth map against the ground truth in ONE kernel and ONE device->host copy (the reference moves
+    each of the K maps to the CPU).  `mask=None` is the reference's ground mask (0 < gt < 1.25 m).
+    Returns (best_index, [err dict per candidate]); best = the first candidate whose mean abs error undercuts the
+    running minimum, starting from 1000 mm as the reference does (None if none does)."""
+    maps = depth_fine_dex if torch.is_tensor(depth_fine_dex) else torch.stack([d.reshape(-1) for d in depth_fine_dex])
+    rows = _ops.dex_error_sweep(depth_gt, maps, None if mask is None else mask.to(depth_gt.device), gt_lo, gt_hi).tolist()
+    errs = [_err_dict(r) for r in rows]
+    best, min_abs = None, 1000.0
+    for i, e in enumerate(errs):
+        if e["depth_abs_err"] < min_abs:
+            best, min_abs = i, e["depth_abs_err"]
+    return best, errs
 
 
 def gen_error_colormap_depth():
@@ -38,7 +63,12 @@ def gen_error_colormap_depth():
 
 def depth_error_img(D_est_tensor, D_gt_tensor, mask, abs_thres=1., dilate_radius=1):
     """Colour-coded |gt - est| / abs_thres image for logging: inputs (B, H, W), returns the first image
-    (H, W, 3) as numpy with the colour legend painted in its top-left corner (reference :46-70)."""
+    (H, W, 3) as numpy with the colour legend painted in its top-left corner (reference :46-70).  Device inputs
+    are coloured by a HIP kernel (one (H,W,3) copy back instead of three input copies)."""
+    if D_gt_tensor.is_cuda:
+        img = _ops.depth_error_image(D_est_tensor.detach()[0], D_gt_tensor.detach()[0], mask.detach()[0].to(D_gt_tensor.device),
+                                     abs_thres)
+        return img.cpu().numpy()
     gt = D_gt_tensor.detach().cpu().numpy()
     est = D_est_tensor.detach().cpu().numpy()
     valid = mask.detach().cpu().numpy().astype(bool)

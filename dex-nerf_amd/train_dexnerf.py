@@ -56,14 +56,11 @@ def render_view(models, cfg, pose, k_mat, size, ex, ed, thres, mode="validation"
 
 
 def dex_sweep(outputs, depth_gt, thres):
-    """Pick the Dex threshold with the smallest mean |depth error| (reference train_dexnerf_rgb.py:391-408)."""
-    mask = (depth_gt > 0) & (depth_gt < 6.0)
-    best = None
-    for m, depth in zip(thres, outputs[6:]):
-        err = nerf.compute_err_metric(depth_gt[None], depth[None], mask[None])
-        if best is None or err["depth_abs_err"] < best[1]["depth_abs_err"]:
-            best = (m, err)
-    return best
+    """Pick the Dex threshold with the smallest mean |depth error| (reference train_dexnerf_rgb.py:391-408): all
+    candidates in one kernel + one copy (nerf.dex_error_sweep); the synthetic scene spans (0, 6) m."""
+    best, errs = nerf.dex_error_sweep(depth_gt, list(outputs[6:]), gt_lo=0.0, gt_hi=6.0)
+    best = int(np.argmin([e["depth_abs_err"] for e in errs])) if best is None else best
+    return thres[best], errs[best]
 
 
 def main(argv=None):
@@ -134,18 +131,20 @@ def main(argv=None):
         opt.load_state_dict(ck["optimizer_state_dict"])
         start = ck["iter"]
     train_ids = list(range(args.views))[rank::world] or [rank % args.views]
+    # one selector per training camera: matrix inverses once, then a single kernel per step from pixel draws to packed
+    # ray rows + target pixels (reference: full-image bundle + coordinate grid + three gathers + normalise + cat)
+    selectors = {v: nerf.RaySelector(args.size, args.size, poses[v], k_mat, 2.0, 6.0, device=dev) for v in train_ids}
     history = []
     t0 = time.perf_counter()
     loss_val = psnr = float("nan")
     for it in range(start, args.iters):
         view = int(np.random.choice(train_ids))
-        ro, rd = nerf.get_ray_bundle(args.size, args.size, float(k_mat[0, 0]), poses[view], k_mat)
-        sel = torch.from_numpy(np.random.choice(args.size * args.size, size=min(args.num_random_rays, args.size ** 2),
-                                                replace=False)).to(dev)
-        out = nerf.run_one_iter_of_nerf(args.size, args.size, float(k_mat[0, 0]), student[0], student[1],
-                                        ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel], cfg, mode="train",
-                                        encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=thres)
-        target = images[view][sel]
+        pix = selectors[view].random_pixels(args.num_random_rays)
+        rays, target = selectors[view].select(pix, images[view].reshape(args.size, args.size, 3))
+        chunks = [nerf.predict_and_render_radiance(batch, student[0], student[1], cfg, mode="train", encode_position_fn=ex,
+                                                   encode_direction_fn=ed, m_thres_cand=thres)
+                  for batch in nerf.get_minibatches(rays, chunksize=args.chunksize)]
+        out = chunks[0] if len(chunks) == 1 else [torch.cat(c, dim=0) for c in zip(*chunks)]
         loss = nerf.img2mse(out[0][..., :3], target) + nerf.img2mse(out[3][..., :3], target)
         bucket.zero()
         loss.backward()

@@ -353,3 +353,62 @@ def mse2psnr(mse):
     """-10 log10(mse), 0 -> 1e-5 guard (nerf/nerf_helpers.py:13-17)."""
     import math
     return -10.0 * math.log10(1e-5 if mse == 0 else mse)
+
+
+# ----------------------------------------------------------------------------------------------
+# validation extras and training-ray selection (SURVEY.md section 8f rows N3 / N4)
+# ----------------------------------------------------------------------------------------------
+def compute_err_metric(depth_gt, depth_pred, mask):
+    """nerf/train_utils.py:9-30: mean |pred*1000 - gt*1000| over the mask and the fractions of masked pixels whose
+    |gt - pred| exceeds 2e-3 / 4e-3 / 8e-3 (all fp32 tensor arithmetic)."""
+    gt, pred = _t(depth_gt), _t(depth_pred)
+    mask = torch.as_tensor(np.asarray(mask), dtype=torch.bool)
+    g, p = gt[mask], pred[mask]
+    diff = torch.abs(g - p)
+    n = diff.numel()
+    return dict(depth_abs_err=torch.mean(torch.abs(p * 1000 - g * 1000)).item(),
+                depth_err2=int((diff > 2e-3).sum()) / n, depth_err4=int((diff > 4e-3).sum()) / n,
+                depth_err8=int((diff > 8e-3).sum()) / n)
+
+
+def error_colormap():
+    """nerf/train_utils.py:31-45: rows [lo, hi, r, g, b] (colours / 255), float32."""
+    edges = [0.0, 0.00001] + [2000.0 / 2 ** e for e in range(10, 1, -1)] + [np.inf]
+    rgb = [(0, 0, 0), (49, 54, 149), (69, 117, 180), (116, 173, 209), (171, 217, 233), (224, 243, 248), (254, 224, 144),
+           (253, 174, 97), (244, 109, 67), (215, 48, 39), (165, 0, 38)]
+    cols = np.array([[edges[i], edges[i + 1], *rgb[i]] for i in range(11)], dtype=np.float32)
+    cols[:, 2:5] /= 255.0
+    return cols
+
+
+def depth_error_img(est, gt, mask, abs_thres=1.0):
+    """nerf/train_utils.py:46-70 for one (H,W) map: colour-coded |gt - est| / abs_thres, masked-out pixels black, the
+    colour legend (20-pixel swatches) over the top ten rows."""
+    est, gt = np.asarray(est, np.float32), np.asarray(gt, np.float32)
+    mask = np.asarray(mask, bool)
+    err = np.abs(gt - est)
+    err[~mask] = 0
+    err[mask] = err[mask] / np.float32(abs_thres)
+    cols = error_colormap()
+    img = np.zeros(gt.shape + (3,), np.float32)
+    for row in cols:
+        img[(err >= row[0]) & (err < row[1])] = row[2:]
+    img[~mask] = 0.0
+    for i, row in enumerate(cols):
+        img[:10, i * 20:(i + 1) * 20, :] = row[2:]
+    return img
+
+
+def select_training_rays(height, width, extrinsic, intrinsic, select_inds, image, near, far):
+    """train_dexnerf_rgb.py:229-242 + nerf/train_utils.py:225-250: the reference enumerates pixels column-major
+    (its coordinate grid is meshgrid_xy(arange(H), arange(W)) flattened, so draw f means pixel (f % H, f // H)),
+    gathers origin / direction / target there, and run_one_iter_of_nerf packs [ro, rd, near, far, rd / ||rd||]."""
+    ro, rd = get_ray_bundle(height, width, extrinsic, intrinsic)
+    f = torch.as_tensor(np.asarray(select_inds), dtype=torch.int64)
+    h, w = f % height, f // height
+    ro_s, rd_s = ro[h, w, :], rd[h, w, :]
+    target = _t(image)[h, w]
+    viewdirs = rd_s / rd_s.norm(p=2, dim=-1).unsqueeze(-1)
+    near_t = near * torch.ones_like(rd_s[..., :1])
+    far_t = far * torch.ones_like(rd_s[..., :1])
+    return torch.cat((ro_s, rd_s, near_t, far_t, viewdirs), dim=-1), target

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Developer helper: build an experiment copy of the library with extra -D flags.
+#   scripts/build_exp.sh NAME "-DDN_EXP_FOO=1" [file.hip ...]   (default: both MLP translation units)
+# Output: exp_libs/libNAME.so (git-ignored; select it with DEXNERF_HIP_LIB=exp_libs/libNAME.so)
+set -e
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+C=$REPO/dex-nerf_amd/csrc
+NAME=$1; FLAGS=$2; shift 2 || true
+FILES=${@:-mlp_fused.hip mlp_train.hip}
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function"
+make -C $C -j8 >/dev/null
+mkdir -p $REPO/exp_libs $C/build/exp_$NAME
+OBJS=""
+for s in api.cpp rays_sampling.hip composite.hip val_metrics.hip mlp_fused.hip mlp_train.hip; do
+  if echo " $FILES " | grep -q " $s "; then
+    /opt/rocm/bin/hipcc $F $FLAGS -I$C -x hip -c $C/$s -o $C/build/exp_$NAME/$s.o &
+    OBJS="$OBJS $C/build/exp_$NAME/$s.o"
+  else
+    OBJS="$OBJS $C/build/$s.o"
+  fi
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $REPO/exp_libs/lib$NAME.so $OBJS
+echo "built exp_libs/lib$NAME.so"

@@ -382,8 +382,73 @@ def d8w256():
                    inject_rand=draws_rand, inject_randn=draws_randn, target=target, save_grads="sub")
 
 
+def val_extras():
+    """the validation error metrics + error image, and the training-ray selection.
+
+    compute_err_metric / depth_error_img are the reference's library functions.  The selection itself lives in the
+    reference's *script* (train_dexnerf_rgb.py:229-242, not importable here: tensorboard / torchvision), so its
+    five lines of index plumbing are spelled out below on the reference's get_ray_bundle / meshgrid_xy, and the packed
+    (N,11) rows are whatever the reference's run_one_iter_of_nerf hands to predict_and_render_radiance."""
+    rng = np.random.default_rng(31)
+    d = {}
+    H, W, K = 24, 240, 6
+    gt = rng.uniform(0.2, 1.6, size=(H, W)).astype(np.float32)
+    gt[rng.uniform(size=(H, W)) < 0.1] = 0.0                       # holes in the ground-truth depth
+    noise = rng.normal(0, 1, size=(K, H, W)).astype(np.float32)
+    scale = np.array([0.0005, 0.002, 0.004, 0.008, 0.03, 0.3], np.float32)[:, None, None]
+    pred = (gt[None] + noise * scale).astype(np.float32)
+    pred[3, :4] = gt[:4]                                           # exact hits (error 0 -> black bin)
+    gt_t = torch.from_numpy(gt)
+    mask = (gt_t > 0) & (gt_t < 1.25)                               # train_dexnerf_rgb.py:392
+    errs = []
+    for k in range(K):
+        e = ref.train_utils.compute_err_metric(gt_t, torch.from_numpy(pred[k]), mask)
+        errs.append([e["depth_abs_err"], e["depth_err2"], e["depth_err4"], e["depth_err8"]])
+    d.update(err_gt=gt, err_pred=pred, err_mask=mask.numpy(), err_out=np.array(errs, np.float64))
+    for k in (1, 4):
+        img = ref.train_utils.depth_error_img(torch.from_numpy(pred[k])[None] * 1000, gt_t[None] * 1000, mask[None])
+        d[f"err_img_{k}"] = img.astype(np.float32)
+    # training-ray selection, 30 x 40 image, 64 rays
+    H, W, n = 30, 40, 64
+    E = torch.from_numpy(syn.scene_pose(3))
+    Kmat = torch.from_numpy(syn.intrinsic(H, W))
+    image = torch.from_numpy(rng.uniform(0, 1, size=(H, W, 4)).astype(np.float32))
+    ro, rd = ref.get_ray_bundle(H, W, float(Kmat[0, 0]), E, Kmat)
+    coords = torch.stack(ref.meshgrid_xy(torch.arange(H), torch.arange(W)), dim=-1).reshape((-1, 2))   # :230-234
+    select_inds = np.random.default_rng(5).choice(coords.shape[0], size=(n), replace=False)               # :235-237
+    sel = coords[select_inds]
+    ro_s, rd_s = ro[sel[:, 0], sel[:, 1], :], rd[sel[:, 0], sel[:, 1], :]                                 # :239-240
+    target_s = image[sel[:, 0], sel[:, 1]]                                                                # :242
+    seen = {}
+    orig = ref.train_utils.predict_and_render_radiance
+
+    def spy(ray_batch, *a, **k):
+        seen["rays"] = ray_batch.detach().clone()
+        return orig(ray_batch, *a, **k)
+
+    kw = dict(num_layers=2, hidden_size=32, skip_connect_every=4, num_encoding_fn_xyz=2, num_encoding_fn_dir=2, use_viewdirs=True)
+    mc = ref.models.FlexibleNeRFModel(**kw)
+    cfg = make_cfg(4, 0, 2.0, 6.0, perturb=False, noise_std=0.0, white=False)
+    ref.train_utils.predict_and_render_radiance = spy
+    try:
+        with torch.no_grad():
+            try:
+                ref.run_one_iter_of_nerf(H, W, float(Kmat[0, 0]), mc, None, ro_s, rd_s, cfg, mode="train",
+                                         encode_position_fn=ref.get_embedding_function(2), encode_direction_fn=ref.get_embedding_function(2),
+                                         m_thres_cand=M_THRES)
+            except Exception:   # the fork raises NameError after a coarse-only pass (train_utils.py:201); the rows are recorded by then
+                pass
+    finally:
+        ref.train_utils.predict_and_render_radiance = orig
+    d.update(sel_E=npf(E), sel_K=npf(Kmat), sel_image=npf(image), sel_inds=select_inds.astype(np.int64), sel_ro=npf(ro_s),
+             sel_rd=npf(rd_s), sel_target=npf(target_s), sel_rays=npf(seen["rays"]), sel_near=2.0, sel_far=6.0)
+    path = os.path.join(HERE, "val_extras.npz")
+    np.savez_compressed(path, **d)
+    print(f"val_extras: {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    kat()
-    lego()
-    d8w256()
+    which = sys.argv[1:] or ["kat", "lego", "d8w256", "val_extras"]
+    for name in which:
+        {"kat": kat, "lego": lego, "d8w256": d8w256, "val_extras": val_extras}[name]()

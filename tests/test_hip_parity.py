@@ -736,3 +736,64 @@ def test_fused_optimizer_step_reaches_the_kernels(dev):
         ref = m._forward_modules(emb)
     assert not torch.allclose(before, after)
     assert rel_err(C(after), C(ref)) < TOL
+
+
+def test_validation_extras_on_device(golden, dev):
+    """N3: the Dex threshold sweep (all candidates, one kernel, one copy) and the error image against the reference's
+    recorded compute_err_metric / depth_error_img outputs: counts and colours exact, mean |err| to 1e-6 relative
+    (fp64 accumulation here, ATen's fp32 mean there)."""
+    import nerf
+    g = golden("val_extras")
+    gt = G(g["err_gt"], dev)
+    pred = G(g["err_pred"], dev)
+    best, errs = nerf.dex_error_sweep(gt, [pred[k] for k in range(pred.shape[0])])      # reference ground mask (0, 1.25)
+    ref = g["err_out"]
+    for k, e in enumerate(errs):
+        assert abs(e["depth_abs_err"] - ref[k, 0]) <= 1e-6 * ref[k, 0]
+        assert [e["depth_err2"], e["depth_err4"], e["depth_err8"]] == list(ref[k, 1:])
+    assert best == int(np.argmin(ref[:, 0])) == 0
+    mask = torch.from_numpy(g["err_mask"]).to(dev)
+    _, errs_m = nerf.dex_error_sweep(gt, pred, mask=mask)                                 # explicit mask, stacked maps
+    assert [e["depth_err4"] for e in errs_m] == list(ref[:, 2])
+    single = nerf.compute_err_metric(gt, pred[3], mask)
+    assert single["depth_err8"] == ref[3, 3] and abs(single["depth_abs_err"] - ref[3, 0]) <= 1e-6 * ref[3, 0]
+    for k in (1, 4):
+        img = nerf.depth_error_img(pred[k][None] * 1000, gt[None] * 1000, mask[None])
+        assert isinstance(img, np.ndarray)
+        np.testing.assert_array_equal(img, g[f"err_img_{k}"])
+
+
+def test_ray_selection_and_ndc_on_device(golden, dev):
+    """N4: one kernel from pixel draws to packed ray rows + target pixels, against the rows the reference's
+    run_one_iter_of_nerf handed to predict_and_render_radiance for the same draws; NDC warp against its golden."""
+    import nerf
+    g = golden("val_extras")
+    sel = nerf.RaySelector(30, 40, torch.from_numpy(g["sel_E"]), torch.from_numpy(g["sel_K"]), float(g["sel_near"]),
+                           float(g["sel_far"]), device=dev)
+    pix = sel.from_reference_choice(g["sel_inds"])
+    rays, target = sel.select(pix, G(g["sel_image"], dev))
+    np.testing.assert_array_equal(C(target), g["sel_target"][:, :3])
+    ref = g["sel_rays"]
+    np.testing.assert_array_equal(C(rays)[:, [0, 1, 2, 6, 7]], ref[:, [0, 1, 2, 6, 7]])   # origin (same host inverse), near, far
+    assert rel_err(C(rays)[:, 3:6], ref[:, 3:6]) < 1e-6 and rel_err(C(rays)[:, 8:], ref[:, 8:]) < 1e-6
+    # the rows feed the render directly
+    kw = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+    from nerf import synthetic as syn
+    m = nerf.models.FlexibleNeRFModel(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(3, **kw).items()})
+    m = m.to(dev)
+    cfg = make_cfg(dict(near=2.0, far=6.0, num_coarse=16, num_fine=0, perturb=False, noise_std=0.0, white=False, lindisp=False))
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    with torch.no_grad():
+        a = nerf.predict_and_render_radiance(rays, m, None, cfg, mode="validation", encode_position_fn=ex, encode_direction_fn=ed)
+        ro, rd = rays[:, :3], rays[:, 3:6]
+        b = nerf.run_one_iter_of_nerf(1, rays.shape[0], 1.0, m, None, ro, rd, cfg, mode="train", encode_position_fn=ex,
+                                      encode_direction_fn=ed)
+    assert rel_err(C(a[0]), C(b[0])) < 1e-5
+    # random draws on the device: distinct, in range
+    p = sel.random_pixels(200)
+    assert p.is_cuda and len(torch.unique(p)) == 200 and int(p.max()) < 1200 and int(p.min()) >= 0
+    k = golden("kat")
+    o, d = nerf.ndc_rays(378, 504, 407.5, 1.0, G(k["ndc_o"], dev), G(k["ndc_d"], dev))
+    np.testing.assert_array_equal(C(o), k["ndc_out_o"])
+    np.testing.assert_array_equal(C(d), k["ndc_out_d"])

@@ -159,3 +159,19 @@ def test_param_key_tracks_fused_optimizer_steps():
         m.layer1.weight.mul_(2.0)   # ordinary in-place op: version bump
     assert m.param_key() != k1
     del versions
+
+
+def test_validation_helpers_host_path(golden):
+    """compute_err_metric / depth_error_img on host tensors (the reference's own composition) against the recorded
+    reference outputs; RaySelector's index conversion from the reference's column-major pixel draws."""
+    import nerf
+    g = golden("val_extras")
+    gt, mask = torch.from_numpy(g["err_gt"]), torch.from_numpy(g["err_mask"])
+    for k in range(g["err_pred"].shape[0]):
+        e = nerf.compute_err_metric(gt, torch.from_numpy(g["err_pred"][k]), mask)
+        assert [e["depth_abs_err"], e["depth_err2"], e["depth_err4"], e["depth_err8"]] == list(g["err_out"][k])
+    img = nerf.depth_error_img(torch.from_numpy(g["err_pred"][1])[None] * 1000, gt[None] * 1000, mask[None])
+    np.testing.assert_array_equal(img, g["err_img_1"])
+    sel = nerf.RaySelector(30, 40, torch.from_numpy(g["sel_E"]), torch.from_numpy(g["sel_K"]), 2.0, 6.0, device="cpu")
+    pix = sel.from_reference_choice(g["sel_inds"])
+    np.testing.assert_array_equal(torch.from_numpy(g["sel_image"]).reshape(-1, 4)[pix].numpy(), g["sel_target"])

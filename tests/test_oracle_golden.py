@@ -186,3 +186,20 @@ def test_render_and_train_goldens(golden, name):
                     assert rel_err(gr.reshape(-1)[::97], g[pref + k + ".sub"]) < 1e-3, k
                     nrm = float(g[pref + k + ".norm"])
                     assert abs(np.linalg.norm(gr.astype(np.float64)) - nrm) < 1e-3 * nrm
+
+
+def test_validation_extras_and_ray_selection(golden):
+    """the oracle's restatements of compute_err_metric, depth_error_img and the training-ray
+    selection equal the reference's recorded outputs exactly."""
+    g = golden("val_extras")
+    for k in range(g["err_pred"].shape[0]):
+        e = oc.compute_err_metric(g["err_gt"], g["err_pred"][k], g["err_mask"])
+        assert [e["depth_abs_err"], e["depth_err2"], e["depth_err4"], e["depth_err8"]] == list(g["err_out"][k])
+    for k in (1, 4):
+        img = oc.depth_error_img(g["err_pred"][k] * np.float32(1000), g["err_gt"] * np.float32(1000), g["err_mask"])
+        np.testing.assert_array_equal(img, g[f"err_img_{k}"])
+    rays, target = oc.select_training_rays(30, 40, g["sel_E"], g["sel_K"], g["sel_inds"], g["sel_image"], 2.0, 6.0)
+    np.testing.assert_array_equal(rays.numpy(), g["sel_rays"])
+    np.testing.assert_array_equal(target.numpy(), g["sel_target"])
+    np.testing.assert_array_equal(rays.numpy()[:, :3], g["sel_ro"])
+    np.testing.assert_array_equal(rays.numpy()[:, 3:6], g["sel_rd"])

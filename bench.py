@@ -97,6 +97,24 @@ def pmc_traffic(precision):
     return json.load(open(path))["hbm_bytes_per_launch"]
 
 
+def library_gemm_tflops(dev, precision):
+    """Yardstick next to the datasheet peak: what the vendor GEMM library (torch a @ b) reaches on this box for a large
+    square GEMM in the same input type (informational; ~15 ms)."""
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(precision, torch.float32)
+    m = 8192
+    a = torch.randn(m, m, device=dev, dtype=dt)
+    b = torch.randn(m, m, device=dev, dtype=dt)
+    for _ in range(3):
+        a @ b
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(10):
+        a @ b
+    ev[1].record()
+    torch.cuda.synchronize()
+    return {"shape": f"{m}^3 {precision}", "tflops": 2.0 * m ** 3 * 10 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12}
+
+
 def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8):
     """Secondary metric (SURVEY.md section 8d ii): rays/s of a full training iteration (perturbed sampling, density
     noise, forward + backward + Adam) on n_rays random rays of the view."""
@@ -256,6 +274,7 @@ def main():
             nerf.set_precision(args.precision)
         if not args.no_train:
             result["train"] = train_rate(models, cfg, ro, rd, ex, ed)
+        result["roofline"]["library_gemm"] = library_gemm_tflops(dev, args.precision)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

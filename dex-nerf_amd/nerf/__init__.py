@@ -3,7 +3,8 @@
 Same public names as the reference's nerf/__init__.py:1-8 star-exports, for the ray-marching hot path:
 ray generation, stratified + hierarchical sampling, positional encoding, the coarse/fine MLPs and
 alpha compositing with the Dex fixed-sigma depth readout all run in hand-written HIP kernels
-(libdexnerf_hip.so) whenever tensors live on the ROCm device.  Dataset loaders are out of scope.
+(libdexnerf_hip.so) whenever tensors live on the ROCm device.  The Blender / MessyTable loaders and the ray-cache format are
+host-side numpy + PIL (nerf/datasets.py); the LLFF loader is not part of this build.
 """
 from . import models, parallel, synthetic  # noqa: F401  (scripts use getattr(models, cfg.models.coarse.type))
 from ._ops import get_precision, set_precision  # noqa: F401
@@ -14,15 +15,5 @@ from .train_utils import *  # noqa: F401,F403
 from .volume_rendering_utils import *  # noqa: F401,F403
 
 
-def _no_loader(name):
-    def loader(*args, **kwargs):
-        raise NotImplementedError(
-            f"{name}: dataset I/O is outside this build's scope (SURVEY.md section 8f, N2); "
-            "feed poses/intrinsics/images as tensors or use nerf.synthetic")
-    loader.__name__ = name
-    return loader
-
-
-load_blender_data = _no_loader("load_blender_data")
-load_llff_data = _no_loader("load_llff_data")
-load_messytable_data = _no_loader("load_messytable_data")
+from .datasets import (load_blender_data, load_llff_data, load_messytable_data, load_ray_cache, pose_spherical,  # noqa: F401,E402
+                       save_ray_cache)

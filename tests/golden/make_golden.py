@@ -442,6 +442,9 @@ def val_extras():
         ref.train_utils.predict_and_render_radiance = orig
     d.update(sel_E=npf(E), sel_K=npf(Kmat), sel_image=npf(image), sel_inds=select_inds.astype(np.int64), sel_ro=npf(ro_s),
              sel_rd=npf(rd_s), sel_target=npf(target_s), sel_rays=npf(seen["rays"]), sel_near=2.0, sel_far=6.0)
+    # camera path of the loaders (nerf/load_blender.py:33-38; importable: only the image readers need cv2 / imageio)
+    angles = np.array([[-180.0, -30.0, 4.0], [37.5, -30.0, 4.0], [90.0, 15.0, 2.5], [171.0, -89.0, 0.3]])
+    d.update(pose_angles=angles, pose_out=np.stack([ref.load_blender.pose_spherical(*a) for a in angles]))
     path = os.path.join(HERE, "val_extras.npz")
     np.savez_compressed(path, **d)
     print(f"val_extras: {os.path.getsize(path) / 1e6:.2f} MB")

@@ -1,0 +1,141 @@
+"""the reference's on-disk formats, read by nerf/datasets.py.  Host-only tests on hand-built scenes
+(the reference's own loaders need cv2 / imageio, absent here: only pose_spherical is pinned to a reference golden)."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+
+def test_pose_spherical_matches_reference_golden(golden):
+    import nerf
+    g = golden("val_extras")
+    out = np.stack([nerf.pose_spherical(*a) for a in g["pose_angles"]])
+    assert out.dtype == g["pose_out"].dtype
+    np.testing.assert_array_equal(out, g["pose_out"])
+
+
+def test_resamplers():
+    from nerf import datasets as D
+    rng = np.random.default_rng(0)
+    img = rng.uniform(0, 1, size=(12, 16, 3)).astype(np.float32)
+    half = D.resize_area(img, 6, 8)                       # integer factor: exact 2x2 block mean
+    np.testing.assert_allclose(half, (img[0::2, 0::2] + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2]) / 4, rtol=1e-6)
+    # non-integer shrink: area-weighted; a constant stays constant and the mean is preserved
+    np.testing.assert_allclose(D.resize_area(np.full((10, 10), 0.25, np.float32), 4, 4), 0.25, rtol=1e-6)
+    small = D.resize_area(img[..., 0], 5, 7)
+    assert small.shape == (5, 7) and abs(float(small.mean()) - float(img[..., 0].mean())) < 1e-6
+    depth = np.arange(12 * 16, dtype=np.float32).reshape(12, 16)
+    np.testing.assert_array_equal(D.resize_nearest(depth, 6, 8), depth[0::2, 0::2])   # floor(dst * 2)
+    np.testing.assert_array_equal(D.resize_nearest(depth, 4, 4), depth[[0, 3, 6, 9]][:, [0, 4, 8, 12]])
+
+
+def _write_blender(root, n_frames=(3, 2, 4), size=8):
+    rng = np.random.default_rng(1)
+    frames = {}
+    for split, n in zip(("train", "val", "test"), n_frames):
+        os.makedirs(os.path.join(root, split), exist_ok=True)
+        meta = {"camera_angle_x": 0.6911112070083618, "frames": []}
+        frames[split] = []
+        for i in range(n):
+            px = rng.integers(0, 256, size=(size, size, 4), dtype=np.uint8)
+            Image.fromarray(px, "RGBA").save(os.path.join(root, split, f"r_{i}.png"))
+            pose = np.eye(4)
+            pose[:3, 3] = rng.normal(size=3)
+            meta["frames"].append({"file_path": f"./{split}/r_{i}", "transform_matrix": pose.tolist()})
+            frames[split].append((px, pose))
+        with open(os.path.join(root, f"transforms_{split}.json"), "w") as fp:
+            json.dump(meta, fp)
+    return frames
+
+
+def test_load_blender_data(tmp_path):
+    import nerf
+    frames = _write_blender(str(tmp_path))
+    imgs, poses, render_poses, hwf, i_split = nerf.load_blender_data(str(tmp_path), half_res=False, testskip=2)
+    # train keeps every frame, val / test every second one
+    assert [len(s) for s in i_split] == [3, 1, 2] and imgs.shape == (6, 8, 8, 4) and imgs.dtype == torch.float32
+    np.testing.assert_array_equal(imgs[0].numpy(), (frames["train"][0][0] / 255.0).astype(np.float32))
+    np.testing.assert_array_equal(imgs[3].numpy(), (frames["val"][0][0] / 255.0).astype(np.float32))
+    np.testing.assert_array_equal(imgs[5].numpy(), (frames["test"][2][0] / 255.0).astype(np.float32))
+    np.testing.assert_array_equal(poses[4].numpy(), frames["test"][0][1].astype(np.float32))
+    assert hwf[:2] == [8, 8] and abs(hwf[2] - 0.5 * 8 / np.tan(0.5 * 0.6911112070083618)) < 1e-9
+    assert render_poses.shape == (40, 4, 4) and render_poses.dtype == torch.float64
+    np.testing.assert_array_equal(render_poses[0].numpy(), nerf.pose_spherical(-180.0, -30.0, 4.0))
+    # the fork's half_res is a QUARTER: size and focal / 4, box-averaged pixels
+    q_imgs, _, _, q_hwf, _ = nerf.load_blender_data(str(tmp_path), half_res=True, testskip=0)
+    assert q_imgs.shape == (9, 2, 2, 4) and q_hwf[:2] == [2, 2] and abs(q_hwf[2] - hwf[2] / 4) < 1e-12
+    full = (frames["train"][1][0] / 255.0).astype(np.float32)
+    np.testing.assert_allclose(q_imgs[1].numpy(), full.reshape(2, 4, 2, 4, 4).mean(axis=(1, 3)), rtol=1e-6)
+
+
+def test_load_blender_debug_thumbnails(tmp_path):
+    """debug=True: 25x25 INTER_AREA thumbnails (non-integer shrink) and H, W, focal / 32 (reference :93-104)."""
+    import nerf
+    _write_blender(str(tmp_path), n_frames=(1, 1, 1), size=64)
+    imgs, _, _, hwf, _ = nerf.load_blender_data(str(tmp_path), debug=True)
+    full, _, _, hwf_full, _ = nerf.load_blender_data(str(tmp_path))
+    assert imgs.shape == (3, 25, 25, 4) and hwf[:2] == [2, 2] and abs(hwf[2] - hwf_full[2] / 32) < 1e-12
+    assert abs(float(imgs[0].mean()) - float(full[0].mean())) < 1e-5   # area weighting preserves the mean
+
+
+def _write_messytable(root, real_rgb=False):
+    rng = np.random.default_rng(2)
+    scenes = {}
+    key_e, key_k, depth_n = ("extrinsic", "intrinsic", "depth.png") if real_rgb else ("extrinsic_l", "intrinsic_l", "depthL.png")
+    for split, n in (("train", 2), ("val", 1), ("test", 1)):
+        for i in range(n):
+            d = os.path.join(root, split, f"{split}-{i}")
+            os.makedirs(d)
+            grey = rng.integers(0, 256, size=(12, 16), dtype=np.uint8)
+            Image.fromarray(grey, "L").save(os.path.join(d, "0128_irL_kuafu_half.png"))
+            depth_mm = rng.integers(300, 4000, size=(12, 16)).astype(np.uint16)
+            Image.fromarray(depth_mm).save(os.path.join(d, depth_n))
+            meta = {key_e: np.eye(4) + rng.normal(size=(4, 4)) * 0.01, key_k: np.array([[1400.0, 0, 960.0], [0, 1400.0, 540.0], [0, 0, 1.0]])}
+            with open(os.path.join(d, "meta.pkl"), "wb") as f:
+                pickle.dump(meta, f)
+            scenes[(split, f"{split}-{i}")] = (grey, depth_mm, meta)
+    return scenes
+
+
+@pytest.mark.parametrize("real_rgb", [False, True])
+def test_load_messytable_data(tmp_path, real_rgb):
+    import nerf
+    scenes = _write_messytable(str(tmp_path), real_rgb)
+    imgs, poses, render_poses, hwf, i_split, intrinsics, depths = nerf.load_messytable_data(str(tmp_path), half_res=True, is_real_rgb=real_rgb)
+    assert [len(s) for s in i_split] == [2, 1, 1]
+    assert imgs.shape == (4, 6, 8, 3) and depths.shape == (4, 6, 8) and intrinsics.shape == (4, 3, 3) and poses.shape == (4, 4, 4)
+    assert hwf[:2] == [6, 8] and hwf[2] == 1400.0 / 4        # always halved maps, focal / 4 (fork quirk)
+    order = {"train": os.listdir(os.path.join(str(tmp_path), "train"))}
+    grey, depth_mm, meta = scenes[("train", order["train"][0])]
+    full = np.repeat((grey / 255.0).astype(np.float32)[..., None], 3, axis=-1)
+    np.testing.assert_allclose(imgs[0].numpy(), full.reshape(6, 2, 8, 2, 3).mean(axis=(1, 3)), rtol=1e-6)
+    np.testing.assert_array_equal(depths[0].numpy(), (depth_mm / 1000).astype(np.float32)[0::2, 0::2])   # mm -> m, nearest
+    k = intrinsics[0].numpy()
+    assert k[0, 0] == 350.0 and k[1, 1] == 350.0 and k[0, 2] == 240.0 and k[1, 2] == 135.0 and k[2, 2] == 1.0
+    key_e = "extrinsic" if real_rgb else "extrinsic_l"
+    np.testing.assert_array_equal(poses[0].numpy(), np.asarray(meta[key_e]).astype(np.float32))
+    _, _, _, _, _, k_full, _ = nerf.load_messytable_data(str(tmp_path), half_res=False, is_real_rgb=real_rgb)
+    assert k_full[0, 0, 0] == 1400.0 and k_full[0, 0, 2] == 960.0
+
+
+def test_ray_cache_round_trip(tmp_path):
+    import nerf
+    ro, rd, tgt = torch.randn(5, 7, 3), torch.randn(5, 7, 3), torch.rand(5, 7, 4)
+    for train in (False, True):
+        path = os.path.join(str(tmp_path), "val" if not train else "train", "0003.data")
+        nerf.save_ray_cache(path, 5, 7, 12.5, ro, rd, tgt, train=train)
+        raw = torch.load(path)
+        assert set(raw) == ({"height", "width", "focal_length", "target", "ray_bundle"} if train else
+                            {"height", "width", "focal_length", "target", "ray_origins", "ray_directions"})
+        h, w, f, ro2, rd2, t2 = nerf.load_ray_cache(path)
+        assert (h, w, f) == (5, 7, 12.5) and torch.equal(ro2, ro) and torch.equal(rd2, rd) and torch.equal(t2, tgt)
+
+
+def test_llff_loader_is_explicitly_absent():
+    import nerf
+    with pytest.raises(NotImplementedError):
+        nerf.load_llff_data("/nonexistent")

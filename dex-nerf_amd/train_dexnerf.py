@@ -3,7 +3,7 @@
 eval_nerf.py:166-206) on the MI355X-native `nerf` package.
 
 What it keeps from the reference loop: one random training view per iteration, `num_random_rays` random pixels,
-loss = MSE(rgb_coarse) + MSE(rgb_fine), PSNR = mse2psnr(loss), Adam with the per-iteration exponential LR
+loss = MSE(rgb_coarse) + MSE(rgb_fine) (or, with --ir, on the luminance of both: train_nerf_ir.py:260-263), PSNR = mse2psnr(loss), Adam with the per-iteration exponential LR
 `lr0 * factor^(i / (lr_decay * 1000))`, validation renders with the Dex threshold sweep
 (`m_thres_cand = arange(5, m_thres + 5, 5)`, best threshold by mean |depth error| on the (0, 1.25 m] mask-style
 validity mask), and the checkpoint dict keys (iter, model_*_state_dict, optimizer_state_dict, loss, psnr).
@@ -79,6 +79,8 @@ def main(argv=None):
     ap.add_argument("--lr-decay", type=int, default=250)
     ap.add_argument("--lr-decay-factor", type=float, default=0.1)
     ap.add_argument("--m-thres", type=int, default=100)
+    ap.add_argument("--ir", action="store_true", help="IR head of train_nerf_ir.py / train_dexnerf_ir.py: MSE on the luminance "
+                                                      "0.299 r + 0.587 g + 0.114 b of prediction and target (:260-263)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--validate-every", type=int, default=500)
     ap.add_argument("--seed", type=int, default=42)
@@ -145,7 +147,11 @@ def main(argv=None):
                                                    encode_direction_fn=ed, m_thres_cand=thres)
                   for batch in nerf.get_minibatches(rays, chunksize=args.chunksize)]
         out = chunks[0] if len(chunks) == 1 else [torch.cat(c, dim=0) for c in zip(*chunks)]
-        loss = nerf.img2mse(out[0][..., :3], target) + nerf.img2mse(out[3][..., :3], target)
+        if args.ir:
+            lum = lambda t: 0.299 * t[..., 0] + 0.587 * t[..., 1] + 0.114 * t[..., 2]  # noqa: E731
+            loss = nerf.img2mse(lum(out[0]), lum(target)) + nerf.img2mse(lum(out[3]), lum(target))
+        else:
+            loss = nerf.img2mse(out[0][..., :3], target) + nerf.img2mse(out[3][..., :3], target)
         bucket.zero()
         loss.backward()
         bucket.all_reduce_mean()              # one flat all-reduce (RCCL over xGMI when world > 1)

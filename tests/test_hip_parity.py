@@ -513,6 +513,21 @@ def test_empty_inputs(dev):
     assert nerf.positional_encoding(torch.zeros(0, 3, device=dev), 10).shape == (0, 63)
 
 
+def test_training_driver_ir_head_and_dex_config_shapes(dev):
+    """BASELINE configs 3 / 5 as shapes: the as-shipped 4x128 nets with the Dex-NeRF sampling (64+64, then 128+256) and
+    the IR luminance loss head; short runs must reduce the loss (bf16 kernels)."""
+    import nerf
+    import train_dexnerf
+    try:
+        for extra in (["--num-coarse", "64", "--num-fine", "64"], ["--num-coarse", "128", "--num-fine", "256", "--ir"]):
+            res = train_dexnerf.main(["--iters", "120", "--size", "24", "--views", "4", "--num-random-rays", "256", "--layers", "4",
+                                      "--width", "128", "--validate-every", "0", "--quiet", "--precision", "bf16"] + extra)
+            first, last = res["history"][0], res["history"][-1]
+            assert np.isfinite(last[1]) and last[1] < 0.5 * first[1], (extra, first, last)
+    finally:
+        nerf.set_precision("fp32")
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_training_driver_learns_a_synthetic_scene(dev, precision):
     """End-to-end: the build-owned driver (reference loop: random view + random rays, MSE_c + MSE_f, Adam with the

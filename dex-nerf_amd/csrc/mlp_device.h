@@ -211,7 +211,9 @@ struct Pipe {
     stage_dst = pend_dst;
     have_stage = true;
 #else
+#ifndef DN_EXP_NOBARRIER   // timing experiment only (UNSAFE: no cross-wave ordering of ring slots)
     __builtin_amdgcn_s_barrier();
+#endif
     advance_issue();
     dma_phase(pend_src, pend_dst, (WAVES == 4 || wave < 4) ? 1u : 0u);
 #endif

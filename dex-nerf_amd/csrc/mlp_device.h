@@ -189,8 +189,13 @@ struct Pipe {
     if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
 #elif defined(DN_EXP_LOOSEWAIT)  // timing experiment only (UNSAFE: lets 8 more VMEM ops stay outstanding)
+#if DN_EXP_LOOSEWAIT >= 2
+    if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(36) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
+#else
     if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+#endif
 #else
     if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -355,6 +360,28 @@ __device__ __forceinline__ void emit_pieces(const f32x16& acc, BO& bo) {
     constexpr int s = decltype(s_c)::value;
     bo[NT * P::PPT + s] = make_piece<BF16, RELU, s>(acc);
   });
+}
+
+// 16-byte store to (wave-uniform base) + lane*16 as ONE instruction with an SGPR base and a single lane-offset VGPR:
+// no per-store 64-bit VGPR address (the training kernels issue ~150 of these per tile; with flat VGPR addressing
+// hipcc spilled pieces in the head stages, and every spill reload waits with vmcnt(0) - draining the HBM stores and
+// the weight pipeline).  `base` must be computed from scalar values only.
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const unsigned long long bits = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits >> 32));
+  return reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+template <class V>
+__device__ __forceinline__ void store16_uniform(const char* base, unsigned lane16, const V& val) {
+  static_assert(sizeof(V) == 16, "one dwordx4 per lane");
+  const char* b = uniform_ptr(base);  // hipcc may have formed the (uniform) address in VGPRs: an "s" operand needs SGPRs
+  const unsigned voff = lane16;
+  const f32x4 data = __builtin_bit_cast(f32x4, val);
+  // s_nop 4: the base may come straight from v_readfirstlane (VALU writes SGPR -> VMEM reads it: 5 wait states), and the
+  // hazard recognizer does not look inside an asm statement
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %[voff], %[data], %[sbase]" : : [voff] "v"(voff), [data] "v"(data), [sbase] "s"(b) : "memory");
 }
 
 // ---- positional encoding straight into B-piece layout -------------------------------------------------

@@ -169,28 +169,26 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
     auto pe_xyz = [&](int t, int k) { return *reinterpret_cast<const BPiece*>(pex + (t * KXP + k) * kPieceBytes); };
     auto no_pe = [&](int, int) { return BPiece{}; };
     // training forward: where this wave's 32-point tile t keeps its saved pieces / mask words
-    auto act_ptr = [&](int t, int slot) {
-      const long long tile32 = (tile * WAVES + wave) * PT + t;
-      return p.act + ((tile32 * p.act_pieces + slot) * 64 + lane) * 16;
+    // this wave's saved-activation record(s) and mask words of the tile: wave-uniform bases, lane offset = lane * 16
+    const char* act_tile[PT];
+    const char* mask_tile_base[PT];
+    if constexpr (SAVE) {
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        const long long tile32 = (tile * WAVES + wave) * PT + t;
+        act_tile[t] = uniform_ptr(p.act + tile32 * p.act_pieces * kPieceBytes);
+        mask_tile_base[t] = uniform_ptr(p.masks + tile32 * p.mask_words * kPieceBytes);
+      }
+    }
+    auto save_piece = [&](int t, int slot, const BPiece& v) {
+      store16_uniform(act_tile[t] + static_cast<long long>(slot) * kPieceBytes, pipe.lane16, v);
     };
     auto save_pieces = [&](auto nt_c, int t, int slot0, const BPiece* pieces) {
 #ifndef DN_EXP_NOSAVE
       if constexpr (SAVE) {
         constexpr int nt = decltype(nt_c)::value;
 #pragma unroll
-        for (int s2 = 0; s2 < P::PPT; ++s2) {
-          char* dst = act_ptr(t, slot0 + nt * P::PPT + s2);
-          const BPiece val = pieces[nt * P::PPT + s2];
-#if defined(DN_EXP_STORE) && DN_EXP_STORE == 1
-          asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(val) : "memory");
-#elif defined(DN_EXP_STORE) && DN_EXP_STORE == 2
-          asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(val) : "memory");
-#elif defined(DN_EXP_STORE) && DN_EXP_STORE == 3
-          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(val) : "memory");
-#else
-          *reinterpret_cast<BPiece*>(dst) = val;
-#endif
-        }
+        for (int s2 = 0; s2 < P::PPT; ++s2) save_piece(t, slot0 + nt * P::PPT + s2, pieces[nt * P::PPT + s2]);
       }
 #endif
     };
@@ -199,20 +197,35 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
 #pragma unroll
       for (int t = 0; t < PT; ++t) { maskw[t][0] = 0u; maskw[t][1] = 0u; maskw[t][2] = 0u; maskw[t][3] = 0u; }
     };
-    auto mask_tile = [&](auto nt_c, int t, const f32x16& acc) {   // bit (nt*16 + r) = acc[r] > 0
+    // ReLU mask bits of output tile nt (layout: relu_mask_bit).  16-bit modes read them off the packed ReLU outputs
+    // (non-zero <=> pre-activation > 0 in the arithmetic the kernel actually ran): one v_pk_min_u16 + one shift-or per
+    // dword instead of compare + select + or per element with sixteen bit constants held in VGPRs.
+    auto mask_tile = [&](auto nt_c, int t, const f32x16& acc, const BPiece* pieces) {
       if constexpr (SAVE) {
         constexpr int nt = decltype(nt_c)::value;
+        if constexpr (BF16) {
+          typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u16x8 one = {1, 1, 1, 1, 1, 1, 1, 1};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) maskw[t][(nt * 16 + r) / 32] |= (acc[r] > 0.0f) ? (1u << ((nt * 16 + r) % 32)) : 0u;
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const u32x4 m = __builtin_bit_cast(u32x4, __builtin_elementwise_min(__builtin_bit_cast(u16x8, pieces[nt * 2 + s2]), one));
+#pragma unroll
+            for (int d = 0; d < 4; ++d) maskw[t][nt / 2] |= m[d] << (s2 * 4 + d + 8 * (nt & 1));
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            maskw[t][relu_mask_bit(nt, r) / 32] |= (acc[r] > 0.0f) ? (1u << (relu_mask_bit(nt, r) % 32)) : 0u;
+        }
       }
     };
     auto mask_store = [&](int word) {
       if constexpr (SAVE) {
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
-          const long long tile32 = (tile * WAVES + wave) * PT + t;
-          uint4 v = make_uint4(maskw[t][0], maskw[t][1], maskw[t][2], maskw[t][3]);
-          *reinterpret_cast<uint4*>(p.masks + ((tile32 * p.mask_words + word) * 64 + lane) * 16) = v;
+          const uint4 v = make_uint4(maskw[t][0], maskw[t][1], maskw[t][2], maskw[t][3]);
+          store16_uniform(mask_tile_base[t] + static_cast<long long>(word) * kPieceBytes, pipe.lane16, v);
         }
       }
     };
@@ -220,12 +233,11 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
 #pragma unroll
       for (int t = 0; t < PT; ++t) {
 #pragma unroll
-        for (int k = 0; k < KXP; ++k) *reinterpret_cast<BPiece*>(act_ptr(t, p.slot_xyz + k)) = pe_xyz(t, k);
+        for (int k = 0; k < KXP; ++k) save_piece(t, p.slot_xyz + k, pe_xyz(t, k));
         if (p.use_viewdirs) {
 #pragma unroll
           for (int k = 0; k < KDP; ++k)
-            *reinterpret_cast<BPiece*>(act_ptr(t, p.slot_dir + k)) =
-                *reinterpret_cast<const BPiece*>(ped + (t * KDP + k) * kPieceBytes);
+            save_piece(t, p.slot_dir + k, *reinterpret_cast<const BPiece*>(ped + (t * KDP + k) * kPieceBytes));
         }
       }
     }
@@ -239,7 +251,7 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
         constexpr int t = decltype(t_c)::value;
         emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bout[t]);
         save_pieces(nt_c, t, p.slot_trunk0 + i * KH, bout[t]);
-        mask_tile(nt_c, t, acc);
+        mask_tile(nt_c, t, acc, bout[t]);
       };
       mask_clear();
       if ((p.skip_mask >> i) & 1u)
@@ -284,7 +296,7 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
                                                constexpr int t = decltype(t_c)::value;
                                                emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bb[t]);
                                                save_pieces(nt_c, t, p.slot_feat, bb[t]);
-                                               mask_tile(nt_c, t, acc);
+                                               mask_tile(nt_c, t, acc, bb[t]);
                                              });
       mask_store(p.D - 1);
       bias_tile += NT + 1;
@@ -298,7 +310,7 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
                                                      constexpr int t = decltype(t_c)::value;
                                                      emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bg[t]);
                                                      save_pieces(nt_c, t, p.slot_dirout, bg[t]);
-                                                     mask_tile(nt_c, t, acc);
+                                                     mask_tile(nt_c, t, acc, bg[t]);
                                                    });
       mask_store(p.D);
       bias_tile += NT / 2;

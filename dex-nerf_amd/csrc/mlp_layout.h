@@ -121,6 +121,11 @@ inline int build_layout(const dn_mlp_desc& d, int precision, NetLayout* out) {
 // Saved-activation slots of the training forward (units: pieces of 1 KiB per 32-point tile), in this order:
 //   [xyz PE | dir PE | layer1 out | trunk 0..D-2 out | fc_feat out | layers_dir.0 out]
 // and one 16-byte ReLU bit-mask word per lane per masked stage (trunk 0..D-2, fc_feat, layers_dir.0).
+// ReLU mask words (training): one 128-bit word per lane per masked stage.  Bit of accumulator register r (0..15) of
+// output tile nt: chosen so that the 16-bit-mode forward can build it from the PACKED outputs (dword j = r/2 of the
+// tile's two pieces holds elements r = 2j (low half) and 2j+1 (high half): v_pk_min_u16(dword, 1) << (j + 8*(nt&1))).
+__host__ __device__ constexpr int relu_mask_bit(int nt, int r) { return 32 * (nt / 2) + (r & 1) * 16 + (r >> 1) + 8 * (nt & 1); }
+
 struct TrainLayout {
   int32_t kpp, epp, ppt;
   int32_t kxp, kdp, kh;             // pieces: xyz PE, dir PE, a W-wide hidden vector

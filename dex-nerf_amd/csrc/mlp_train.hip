@@ -79,7 +79,7 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
         const unsigned words[4] = {mw->x, mw->y, mw->z, mw->w};
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const bool on = (words[(nt * 16 + r) / 32] >> ((nt * 16 + r) % 32)) & 1u;
+          const bool on = (words[relu_mask_bit(nt, r) / 32] >> (relu_mask_bit(nt, r) % 32)) & 1u;
           acc[r] = on ? acc[r] : 0.0f;
         }
       }

@@ -379,9 +379,12 @@ __device__ __forceinline__ void store16_uniform(const char* base, unsigned lane1
   const char* b = uniform_ptr(base);  // hipcc may have formed the (uniform) address in VGPRs: an "s" operand needs SGPRs
   const unsigned voff = lane16;
   const f32x4 data = __builtin_bit_cast(f32x4, val);
-  // s_nop 4: the base may come straight from v_readfirstlane (VALU writes SGPR -> VMEM reads it: 5 wait states), and the
-  // hazard recognizer does not look inside an asm statement
-  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %[voff], %[data], %[sbase]" : : [voff] "v"(voff), [data] "v"(data), [sbase] "s"(b) : "memory");
+  // The hazard recognizer does not look inside an asm statement, so the wait states are spelled out:
+  //   s_nop 4 before: the base may come straight from v_readfirstlane (VALU writes SGPR -> VMEM reads it: 5 wait states);
+  //   s_nop 1 after: a store of more than 8 bytes still reads its data VGPRs when the next instruction issues - a VALU
+  //   write to them there corrupts the stored dwords (seen: hipcc reuses the piece registers at once).
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %[voff], %[data], %[sbase]\n\ts_nop 1"
+               : : [voff] "v"(voff), [data] "v"(data), [sbase] "s"(b) : "memory");
 }
 
 // ---- positional encoding straight into B-piece layout -------------------------------------------------

@@ -27,6 +27,25 @@ struct BwdParams {
   int gslot_dirout, gslot_feat, gslot_trunk0, gslot_layer1, gslot_out;
 };
 
+constexpr int kBwdWaveLds = 6 * kPieceBytes;  // per wave: 2 output-gradient slots + 4 mask-word slots (1 KiB each)
+
+// 16 B per lane, per-lane global address -> LDS (M0 base + lane*16), as an opaque instruction: the counted waits of
+// the weight pipeline cover it (it is issued >= 3 phases before its data is read) and hipcc never waits on it.
+__device__ __forceinline__ void dma16_lanes(const void* src_lane, unsigned lds_addr) {
+  const unsigned lds = __builtin_amdgcn_readfirstlane(lds_addr);
+  const void* src = src_lane;
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %[keep], m0\n\t"
+      "s_mov_b32 m0, %[lds]\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[vaddr], off\n\t"
+      "s_mov_b32 m0, %[keep]"
+      : [keep] "=&s"(keep)
+      : [lds] "s"(lds), [vaddr] "v"(src)
+      : "memory");
+}
+
 template <int W, int BF16>
 __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void mlp_backward_kernel(BwdParams p) {
   using P = Prec<BF16>;
@@ -42,6 +61,22 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5;
   const int j = lane & 31;
+  // per-wave staging: the output gradient rows of the NEXT tile and the ReLU mask words two stages ahead arrive by
+  // LDS-DMA; no VGPR-destination global load exists in the tile loop (a wait on one would also wait for every older
+  // store - HBM latency - and for the weight DMAs)
+  char* wbuf = smem + kRingBytes + wave * kBwdWaveLds;
+  const unsigned wbuf_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)wbuf));
+  const int n_masks = p.mask_words;          // stage q < n_masks applies mask word n_masks-1-q; stage n_masks: none
+
+  auto issue_gout = [&](long long tile, int slot) {
+    long long pt = (tile * WAVES + wave) * 32 + j;
+    if (pt >= p.n_points) pt = p.n_points - 1;  // clamped lanes recompute a valid point; their stores hit padding tiles
+    dma16_lanes(p.g_out + pt * 4, wbuf_addr + slot * kPieceBytes);
+  };
+  auto issue_mask = [&](long long tile, int q) {  // mask word of stage q of `tile` -> slot q & 3
+    const char* src = p.masks + (((tile * WAVES + wave) * p.mask_words + (n_masks - 1 - q)) * 64 + lane) * 16;
+    dma16_lanes(src, wbuf_addr + (2 + (q & 3)) * kPieceBytes);
+  };
 
   Pipe<WAVES> pipe;
   pipe.ring = ring;
@@ -52,6 +87,9 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
   pipe.q_issue = 0;
   pipe.slot_wr = 0;
   pipe.wave = wave;
+  issue_gout(blockIdx.x, 0);
+  issue_mask(blockIdx.x, 0);
+  if (n_masks > 1) issue_mask(blockIdx.x, 1);
 #pragma unroll
   for (int ph = 0; ph < kRingPhases - 1; ++ph) pipe.issue_phase();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -62,40 +100,72 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
 #pragma unroll
   for (int e = 0; e < kPrefetch; ++e) pipe.af[e] = *reinterpret_cast<const f32x4*>(pipe.rd_nxt + e * kPieceBytes);
 
+  int g_slot = 0;
   for (long long tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
     const long long tile32 = tile * WAVES + wave;
-    long long pt = tile32 * 32 + j;
-    if (pt >= p.n_points) pt = p.n_points - 1;  // clamped lanes recompute a valid point; their stores hit padding tiles
-    const f32x4 g = *reinterpret_cast<const f32x4*>(p.g_out + pt * 4);
-    const char* mask_base = p.masks + (tile32 * p.mask_words * 64 + lane) * 16;
-    auto load_mask = [&](int word) { return *reinterpret_cast<const uint4*>(mask_base + static_cast<long long>(word) * 1024); };
-    char* grad_base = p.grads + (tile32 * p.grad_pieces * 64 + lane) * 16;
+    const long long nxt = tile + gridDim.x;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(wbuf + g_slot * kPieceBytes + lane * 16);
+    const char* grad_tile = uniform_ptr(p.grads + tile32 * p.grad_pieces * kPieceBytes);
+    auto store_grad = [&](int slot, const BPiece& v) {
+#ifndef DN_EXP_NOSAVE
+      store16_uniform(grad_tile + static_cast<long long>(slot) * kPieceBytes, pipe.lane16, v);
+#endif
+    };
+    // Start of stage q: fetch this stage's mask word from its LDS slot, then stage what will be needed two stages on
+    // (same tile, or the first two stages / the output gradient of the next tile) into the slot just read or one idle
+    // for two stages.  The LDS read is complete (lgkmcnt(0)) before a DMA may overwrite the slot.
+    auto stage_begin = [&](int q) {
+      uint4 mw = make_uint4(~0u, ~0u, ~0u, ~0u);
+      if (q < n_masks) mw = *reinterpret_cast<const uint4*>(wbuf + (2 + (q & 3)) * kPieceBytes + lane * 16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int r = q + 2;
+      if (r < n_masks) issue_mask(tile, r);
+      else if (r > n_masks && nxt < p.n_tiles) {   // r == n_masks + 1 / + 2: stages 0 / 1 of the next tile
+        const int r2 = r - (n_masks + 1);
+        if (r2 < n_masks) issue_mask(nxt, r2);
+        if (r2 == 0) issue_gout(nxt, g_slot ^ 1);
+      }
+      return mw;
+    };
 
     // masked gradient tile -> next stage's B pieces + one store per piece
-    auto emit_grad = [&](auto nt_c, const f32x16& acc_in, const uint4* mw, BPiece* bout, int gslot) {
+    auto emit_grad = [&](auto nt_c, const f32x16& acc_in, const uint4& mw, BPiece* bout, int gslot) {
       constexpr int nt = decltype(nt_c)::value;
-      f32x16 acc = acc_in;
-      if (mw != nullptr) {
-        const unsigned words[4] = {mw->x, mw->y, mw->z, mw->w};
+      if constexpr (BF16) {
+        // convert first, then mask the PACKED pairs: dword j of the tile's two pieces holds registers 2j / 2j+1, whose
+        // mask bits sit at (j + 8*(nt&1)) and 16 + that (relu_mask_bit): (bits & 0x00010001) * 0xFFFF = the AND mask
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const unsigned word = nt / 2 == 0 ? mw.x : nt / 2 == 1 ? mw.y : nt / 2 == 2 ? mw.z : mw.w;
+        static_for<P::PPT>([&](auto s_c) {
+          constexpr int s = decltype(s_c)::value;
+          u32x4 bits = __builtin_bit_cast(u32x4, make_piece<BF16, false, s>(acc_in));
+#pragma unroll
+          for (int d = 0; d < 4; ++d) bits[d] &= ((word >> (s * 4 + d + 8 * (nt & 1))) & 0x00010001u) * 0xFFFFu;
+          const BPiece piece = __builtin_bit_cast(BPiece, bits);
+          bout[nt * P::PPT + s] = piece;
+          store_grad(gslot + nt * P::PPT + s, piece);
+        });
+      } else {
+        f32x16 acc = acc_in;
+        const unsigned words[4] = {mw.x, mw.y, mw.z, mw.w};
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const bool on = (words[relu_mask_bit(nt, r) / 32] >> (relu_mask_bit(nt, r) % 32)) & 1u;
           acc[r] = on ? acc[r] : 0.0f;
         }
+        static_for<P::PPT>([&](auto s_c) {
+          constexpr int s = decltype(s_c)::value;
+          const BPiece piece = make_piece<BF16, false, s>(acc);
+          bout[nt * P::PPT + s] = piece;
+          store_grad(gslot + nt * P::PPT + s, piece);
+        });
       }
-      static_for<P::PPT>([&](auto s_c) {
-        constexpr int s = decltype(s_c)::value;
-        const BPiece piece = make_piece<BF16, false, s>(acc);
-        bout[nt * P::PPT + s] = piece;
-#ifndef DN_EXP_NOSAVE
-        *reinterpret_cast<BPiece*>(grad_base + static_cast<long long>(gslot + nt * P::PPT + s) * 1024) = piece;
-#endif
-      });
     };
 
     BPiece ba[PT][KH], bb[PT][KH];
     BPiece none[PT][1];
     auto no_pe = [&](int, int) { return BPiece{}; };
+    int q = 0;  // stage counter of this tile
     if (p.use_viewdirs) {
       // custom input pieces: element (half 0, e) carries k = e
       BPiece crgb{}, calpha{};
@@ -108,28 +178,26 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
           calpha[0] = g[3];
         }
       }
-      *reinterpret_cast<BPiece*>(grad_base + static_cast<long long>(p.gslot_out) * 1024) = crgb;      // for dW(fc_rgb)
-      *reinterpret_cast<BPiece*>(grad_base + static_cast<long long>(p.gslot_out + 1) * 1024) = calpha;  // for dW(fc_alpha)
+      store_grad(p.gslot_out, crgb);        // for dW(fc_rgb)
+      store_grad(p.gslot_out + 1, calpha);  // for dW(fc_alpha)
       // ---- d g = fc_rgb^T d rgb, masked by relu'(layers_dir.0 out) ----
-      uint4 mw = load_mask(p.D);
-      uint4 mw_next = load_mask(p.D - 1);
+      uint4 mw = stage_begin(q++);
       auto c_rgb = [&](int, int) { return crgb; };
       run_stage<BF16, PT, NT / 2, 0, 1, 0, false>(pipe, none, c_rgb, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
-        emit_grad(nt_c, acc, &mw, ba[0], p.gslot_dirout);
+        emit_grad(nt_c, acc, mw, ba[0], p.gslot_dirout);
       });
       // ---- d feat = layers_dir.0[:, :W]^T d dirpre, masked by relu'(fc_feat out) ----
       constexpr int P1 = (NT / 2) % kPhasePieces;
-      mw = mw_next;
-      mw_next = load_mask(p.D - 2);
+      mw = stage_begin(q++);
       run_stage<BF16, PT, NT, KH / 2, 0, P1, false>(pipe, ba, no_pe, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
-        emit_grad(nt_c, acc, &mw, bb[0], p.gslot_feat);
+        emit_grad(nt_c, acc, mw, bb[0], p.gslot_feat);
       });
       // ---- d h = fc_feat^T d featpre + fc_alpha^T d alpha, masked by relu'(layers_xyz[D-2] out) ----
       constexpr int P2 = (P1 + NT * (KH / 2)) % kPhasePieces;
-      mw = mw_next;
+      mw = stage_begin(q++);
       auto c_alpha = [&](int, int) { return calpha; };
       run_stage<BF16, PT, NT, KH, 1, P2, false>(pipe, bb, c_alpha, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
-        emit_grad(nt_c, acc, &mw, ba[0], p.gslot_trunk0 + (p.D - 2) * KH);
+        emit_grad(nt_c, acc, mw, ba[0], p.gslot_trunk0 + (p.D - 2) * KH);
       });
     } else {
       // ---- d h = fc_out^T d out, masked by relu'(layers_xyz[D-2] out) ----
@@ -140,41 +208,39 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
           if constexpr (BF16) cout[c] = static_cast<__bf16>(g[c]); else cout[c] = g[c];
         }
       }
-      *reinterpret_cast<BPiece*>(grad_base + static_cast<long long>(p.gslot_out) * 1024) = cout;  // for dW(fc_out)
-      uint4 mw = load_mask(p.D - 2);
+      store_grad(p.gslot_out, cout);  // for dW(fc_out)
+      const uint4 mw = stage_begin(q++);
       auto c_out = [&](int, int) { return cout; };
       run_stage<BF16, PT, NT, 0, 1, 0, false>(pipe, none, c_out, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
-        emit_grad(nt_c, acc, &mw, ba[0], p.gslot_trunk0 + (p.D - 2) * KH);
+        emit_grad(nt_c, acc, mw, ba[0], p.gslot_trunk0 + (p.D - 2) * KH);
       });
     }
-    // ---- trunk, i = D-2 .. 0:  d x_i = layers_xyz[i][:, :W]^T d pre_i, masked by relu'(x_i) (x_0 = layer1 out: no mask)
-    //      `ba` holds d pre_i on entry.  Positions: both head variants leave the same offset mod 16 per precision/W.
+    // ---- trunk, i = D-2 .. 0:  d x_i = layers_xyz[i][:, :W]^T d pre_i, masked by relu'(x_i) (x_0 = layer1 out: the
+    //      last stage has no mask word - stage_begin hands back all ones).  The gradient sets ping-pong between `ba`
+    //      and `bb`.  Positions: both head variants leave the same offset mod 16 per precision/W.
     constexpr int PV = ((NT / 2) + NT * (KH / 2) + NT * (KH + 1)) % kPhasePieces;  // viewdirs head
     constexpr int PN = NT % kPhasePieces;                                            // fc_out head
     auto trunk = [&](auto pos_c) {
       constexpr int POS = decltype(pos_c)::value;
-      // mask words are fetched one stage ahead so the load is long complete at its first use
-      uint4 mw_nxt = (p.D - 3 >= 0) ? load_mask(p.D - 3) : make_uint4(0u, 0u, 0u, 0u);
-      for (int i = p.D - 2; i >= 0; --i) {
-        const uint4 mw = mw_nxt;
-        if (i - 2 >= 0) mw_nxt = load_mask(i - 2);
-        if (i > 0) {
-          run_stage<BF16, PT, NT, KH, 0, POS, false>(pipe, ba, no_pe, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
-            emit_grad(nt_c, acc, &mw, bb[0], p.gslot_trunk0 + (i - 1) * KH);
-          });
-        } else {
-          run_stage<BF16, PT, NT, KH, 0, POS, false>(pipe, ba, no_pe, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
-            emit_grad(nt_c, acc, nullptr, bb[0], p.gslot_layer1);
-          });
-        }
-#pragma unroll
-        for (int k = 0; k < KH; ++k) ba[0][k] = bb[0][k];
+      auto layer = [&](int i, const BPiece (&bin)[PT][KH], BPiece (&bout)[PT][KH]) {
+        const uint4 mw = stage_begin(q++);
+        const int gslot = i > 0 ? p.gslot_trunk0 + (i - 1) * KH : p.gslot_layer1;
+        run_stage<BF16, PT, NT, KH, 0, POS, false>(pipe, bin, no_pe, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
+          emit_grad(nt_c, acc, mw, bout[0], gslot);
+        });
+      };
+      int i = p.D - 2;
+      for (; i >= 1; i -= 2) {
+        layer(i, ba, bb);
+        layer(i - 1, bb, ba);
       }
+      if (i == 0) layer(0, ba, bb);
       if constexpr (POS % kPhasePieces != 0) pipe.template skip<POS, kPhasePieces - POS>();
     };
     static_assert((NT * KH) % kPhasePieces == 0, "trunk stages must preserve the phase offset");
     if (p.use_viewdirs) trunk(std::integral_constant<int, PV>{});
     else trunk(std::integral_constant<int, PN>{});
+    g_slot ^= 1;
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
@@ -221,7 +287,7 @@ static int launch_backward(BwdParams p, hipStream_t stream) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
   const long long grid = p.n_tiles < cus ? p.n_tiles : cus;
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(WAVES * 64), kRingBytes, stream, p);
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(WAVES * 64), kRingBytes + WAVES * kBwdWaveLds, stream, p);
   return check_launch("mlp_backward");
 }
 

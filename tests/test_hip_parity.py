@@ -812,3 +812,51 @@ def test_ray_selection_and_ndc_on_device(golden, dev):
     o, d = nerf.ndc_rays(378, 504, 407.5, 1.0, G(k["ndc_o"], dev), G(k["ndc_d"], dev))
     np.testing.assert_array_equal(C(o), k["ndc_out_o"])
     np.testing.assert_array_equal(C(d), k["ndc_out_d"])
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_backward_chain_stages_against_matmul(dev, precision):
+    """Kernel-level check of the backward-data chain on its own buffers: every trunk stage's stored gradient must equal
+    (next stage's stored gradient) @ W masked by the saved ReLU pattern, recomputed here with plain matmuls from the
+    unpacked native buffers.  Catches data-path faults that the end-to-end cosine checks only see as a small loss of
+    accuracy (e.g. a store racing a register reuse corrupts one dword in a few lanes)."""
+    import nerf
+    from nerf import _ops, _train, synthetic as syn
+    nerf.set_precision(precision)
+    try:
+        kw = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+        m = nerf.models.FlexibleNeRFModel(**kw)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(43, sigma_bias=-20.0, **kw).items()})
+        m = m.to(dev)
+        pk = m.packed()
+        _ops.pack_backward(pk, [x.weight for x in m.linear_modules()])
+        torch.manual_seed(0)
+        n_rays, s = 41, 24          # 984 points: the last workgroup tile is ragged
+        pts = torch.randn(n_rays * s, 3, device=dev)
+        vd = torch.nn.functional.normalize(torch.randn(n_rays, 3, device=dev), dim=-1)
+        out, act, masks = _ops.run_network_train(pk, pts, vd, s)
+        n = out.shape[0]
+        grads = _ops.mlp_backward_data(pk, torch.randn(n, 4, device=dev), masks, n)
+        slots, gslots, kh = _train._slots(m, pk.precision)
+        w = m.hidden_size
+
+        def rows(which, buf, slot):
+            return _ops.mlp_unpack(pk, which, buf, n, slot, w, 0, torch.empty((n, w), dtype=torch.float32, device=dev))
+
+        lowp = (lambda t: t.to(torch.bfloat16).float()) if precision == "bf16" else (lambda t: t)
+        tol = 1.5e-2 if precision == "bf16" else 1e-5     # bf16: the stored gradient is rounded to 8 bits
+        d_next = rows(1, grads, gslots["trunk0"] + (m.num_layers - 2) * kh)       # d pre-activation of layers_xyz[D-2]
+        for i in range(m.num_layers - 2, -1, -1):
+            weight = lowp(m.layers_xyz[i].weight.detach()[:, :w])
+            d_x = d_next @ weight                                                   # d (input of layers_xyz[i])
+            if i > 0:
+                x_i = rows(0, act, slots["trunk0"] + (i - 1) * kh)                  # = relu(pre_{i-1}) saved by the forward
+                expect = d_x * (x_i > 0)
+                got = rows(1, grads, gslots["trunk0"] + (i - 1) * kh)
+            else:
+                expect = d_x                                                        # layer1 has no activation
+                got = rows(1, grads, gslots["layer1"])
+            assert rel_err(C(got), C(expect)) < tol, (precision, i, rel_err(C(got), C(expect)))
+            d_next = got
+    finally:
+        nerf.set_precision("fp32")

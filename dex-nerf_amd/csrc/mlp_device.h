@@ -120,6 +120,9 @@ struct Pipe {
   // branch *inside* the asm so the compiler sees straight-line code (a C++ branch here splits every phase into
   // basic blocks and costs dozens of spilled registers).  The instruction offset advances both the global and
   // the LDS address.  hipcc does not count these in its own waitcnt bookkeeping - the counted waits are ours.
+  // Hazards the recognizer cannot see inside the statement: the SGPR base comes from v_readfirstlane (VALU writes SGPR ->
+  // VMEM reads it: 5 wait states = the five scalar instructions ahead of the load, s_nop 1 for margin) and M0 is
+  // written one instruction + nop before the LDS-DMA reads it.
   __device__ __forceinline__ void dma_phase(unsigned src_off, unsigned dst_off, unsigned go) {
 #ifndef DN_EXP_NODMA
     // every "s" operand must be provably wave-uniform: readfirstlane them (they are uniform by construction)
@@ -136,7 +139,7 @@ struct Pipe {
           "s_cbranch_scc0 .Ldn_dma_skip%=\n\t"
           "s_mov_b32 %[keep], m0\n\t"
           "s_mov_b32 m0, %[lds]\n\t"
-          "s_nop 0\n\t"
+          "s_nop 1\n\t"
           "global_load_lds_dwordx4 %[voff], %[sbase]\n\t"
           "global_load_lds_dwordx4 %[voff], %[sbase] offset:1024\n\t"
           "s_mov_b32 m0, %[keep]\n"
@@ -150,7 +153,7 @@ struct Pipe {
           "s_cbranch_scc0 .Ldn_dma_skip%=\n\t"
           "s_mov_b32 %[keep], m0\n\t"
           "s_mov_b32 m0, %[lds]\n\t"
-          "s_nop 0\n\t"
+          "s_nop 1\n\t"
           "global_load_lds_dwordx4 %[voff], %[sbase]\n\t"
           "global_load_lds_dwordx4 %[voff], %[sbase] offset:1024\n\t"
           "global_load_lds_dwordx4 %[voff], %[sbase] offset:2048\n\t"

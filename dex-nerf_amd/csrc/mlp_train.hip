@@ -38,7 +38,7 @@ __device__ __forceinline__ void dma16_lanes(const void* src_lane, unsigned lds_a
   asm volatile(
       "s_mov_b32 %[keep], m0\n\t"
       "s_mov_b32 m0, %[lds]\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "global_load_lds_dwordx4 %[vaddr], off\n\t"
       "s_mov_b32 m0, %[keep]"
       : [keep] "=&s"(keep)
@@ -577,7 +577,7 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
           "s_cbranch_scc0 .Ldn_wg_skip%=\n\t"
           "s_mov_b32 %[keep], m0\n\t"
           "s_mov_b32 m0, %[lds]\n\t"
-          "s_nop 0\n\t"
+          "s_nop 1\n\t"
           "global_load_lds_dwordx4 %[voff], %[sbase]" DN_WG_LOAD_POLICY "\n\t"
           "s_mov_b32 m0, %[keep]\n"
           ".Ldn_wg_skip%=:"

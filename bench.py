@@ -250,6 +250,8 @@ def main():
                          "traffic": pmc_traffic(args.precision), "kernel": "mlp_forward_kernel<256,10,4> (fine net, 160000x192 points)",
                          "kernel_ms": kt * 1e3, "whole_path_tflops": whole_tf},
         }
+        if world > 1:
+            args.no_cpu_baseline = True   # the CPU baseline is reported at N=1 only
         if not args.no_cpu_baseline:
             cb, sel, ref = cpu_baseline()
             result["cpu_baseline"] = cb
@@ -272,7 +274,7 @@ def main():
             result["fp16_mode"] = {"value": H * W / dt16, "unit": "rays/s",
                                    "psnr_vs_oracle_db": float(-10.0 * np.log10(max(mse16, 1e-12)))}
             nerf.set_precision(args.precision)
-        if not args.no_train:
+        if not args.no_train and world == 1:
             result["train"] = train_rate(models, cfg, ro, rd, ex, ed)
         result["roofline"]["library_gemm"] = library_gemm_tflops(dev, args.precision)
         print(json.dumps(result), flush=True)

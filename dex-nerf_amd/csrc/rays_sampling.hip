@@ -74,6 +74,49 @@ __global__ void select_rays_kernel(RayBundleArgs a, float near, float far, const
   }
 }
 
+// The same with the camera chosen on the device: `cams` holds one 16-float record per training view
+// [rinv9, origin3, fx, cx, cy, -] and `view` is a device scalar, so a captured HIP graph of the whole training
+// iteration can be replayed for any view (host-side camera constants would be frozen into the graph).
+__global__ void select_rays_indirect_kernel(const float* __restrict__ cams, const int* __restrict__ view, int height, int width,
+                                            float near, float far, const int64_t* __restrict__ pix, int64_t n,
+                                            const float* __restrict__ images, int channels, float* __restrict__ rays,
+                                            float* __restrict__ target) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int v = *view;
+  const float* cam = cams + static_cast<int64_t>(v) * 16;
+  const float fx = cam[12], cx = cam[13], cy = cam[14];
+  const int64_t px = pix[i];
+  const int row = static_cast<int>(px / width);
+  const int col = static_cast<int>(px - static_cast<int64_t>(row) * width);
+  const float d0 = (static_cast<float>(col) - cx) / fx;
+  const float d1 = (static_cast<float>(row) - cy) / fx;
+  const float d2 = 1.0f;
+  float rd[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float p0 = d0 * cam[3 * j + 0];
+    const float p1 = d1 * cam[3 * j + 1];
+    const float p2 = d2 * cam[3 * j + 2];
+    rd[j] = (p0 + p1) + p2;
+  }
+  const float nrm = sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);
+  float* r = rays + i * 11;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    r[j] = cam[9 + j];
+    r[3 + j] = rd[j];
+    r[8 + j] = rd[j] / nrm;
+  }
+  r[6] = near;
+  r[7] = far;
+  if (target != nullptr) {
+    const float* img = images + static_cast<int64_t>(v) * height * width * channels;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) target[i * 3 + c] = img[px * channels + c];
+  }
+}
+
 // Forward-facing NDC warp (reference nerf/nerf_helpers.py:172-199), op for op (compiled -ffp-contract=off).
 __global__ void ndc_rays_kernel(double h, double w, double focal, double near_d, const float* __restrict__ ro,
                                 const float* __restrict__ rd, int64_t n, float* __restrict__ ro_out,
@@ -356,6 +399,19 @@ extern "C" int dn_select_rays(int height, int width, const float* h_rinv9, const
   hipLaunchKernelGGL(select_rays_kernel, dim3(grid), dim3(block), 0, as_stream(stream), a, near, far, pixel_index, n_rays,
                      image, channels, rays, target);
   return check_launch("dn_select_rays");
+}
+
+extern "C" int dn_select_rays_indirect(int height, int width, const float* cams, const int32_t* view, float near,
+                                       float far, const int64_t* pixel_index, int64_t n_rays, const float* images,
+                                       int channels, float* rays, float* target, dn_stream_t stream) {
+  if (n_rays == 0) return 0;
+  DN_REQUIRE(height > 0 && width > 0 && cams && view && pixel_index && rays && n_rays >= 0, "dn_select_rays_indirect: bad arguments");
+  DN_REQUIRE(target == nullptr || (images != nullptr && channels >= 3), "dn_select_rays_indirect: target requested without images of >= 3 channels");
+  const int block = 256;
+  const unsigned grid = static_cast<unsigned>((n_rays + block - 1) / block);
+  hipLaunchKernelGGL(select_rays_indirect_kernel, dim3(grid), dim3(block), 0, as_stream(stream), cams, view, height, width, near,
+                     far, pixel_index, n_rays, images, channels, rays, target);
+  return check_launch("dn_select_rays_indirect");
 }
 
 extern "C" int dn_ndc_rays(int height, int width, double focal, double near, const float* rays_o, const float* rays_d,

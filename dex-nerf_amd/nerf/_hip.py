@@ -23,7 +23,7 @@ EXPORTS = (
     "dn_volume_render_backward", "dn_sample_pdf", "dn_fine_depths", "dn_render_workspace_bytes", "dn_render_rays",
     "dn_mlp_train_sizes", "dn_mlp_backward_packed_bytes", "dn_mlp_pack_backward", "dn_run_network_train",
     "dn_mlp_backward_data", "dn_mlp_unpack", "dn_mlp_weight_grad", "dn_mlp_weight_grad_all",
-    "dn_select_rays", "dn_ndc_rays", "dn_dex_error_sweep", "dn_depth_error_image",
+    "dn_select_rays", "dn_select_rays_indirect", "dn_ndc_rays", "dn_dex_error_sweep", "dn_depth_error_image",
 )
 
 
@@ -72,6 +72,7 @@ def _declare(lib):
                                        fp, vp]
     lib.dn_select_rays.argtypes = [c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float, c_float, c_float, c_float,
                                    vp, c_int64, fp, c_int, fp, fp, vp]
+    lib.dn_select_rays_indirect.argtypes = [c_int, c_int, fp, vp, c_float, c_float, vp, c_int64, fp, c_int, fp, fp, vp]
     lib.dn_ndc_rays.argtypes = [c_int, c_int, ctypes.c_double, ctypes.c_double, fp, fp, c_int64, fp, fp, vp]
     lib.dn_dex_error_sweep.argtypes = [fp, fp, c_int, c_int64, vp, c_float, c_float, vp, vp]
     lib.dn_depth_error_image.argtypes = [fp, fp, vp, c_int, c_int, c_float, fp, vp]

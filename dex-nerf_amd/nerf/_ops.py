@@ -58,6 +58,22 @@ def select_rays(height, width, rinv, origin, fx, cx, cy, near, far, pixel_index,
     return rays, target
 
 
+def select_rays_indirect(height, width, cams, view, near, far, pixel_index, images=None):
+    """select_rays with the camera record chosen by the device scalar `view` (int32) out of `cams` (V,16)."""
+    pix = pixel_index.contiguous()
+    assert pix.dtype == torch.int64 and view.dtype == torch.int32 and cams.dtype == torch.float32 and cams.is_contiguous()
+    n = pix.numel()
+    rays = torch.empty((n, 11), dtype=torch.float32, device=pix.device)
+    target, img, channels = None, None, 0
+    if images is not None:
+        img = f32c(images)
+        channels = img.shape[-1]
+        target = torch.empty((n, 3), dtype=torch.float32, device=pix.device)
+    check(lib().dn_select_rays_indirect(height, width, ptr(cams), ptr(view), float(near), float(far), ptr(pix), n, ptr(img), channels,
+                                        ptr(rays), ptr(target), stream()), "dn_select_rays_indirect")
+    return rays, target
+
+
 def ndc_rays(height, width, focal, near, rays_o, rays_d):
     ro, rd = f32c(rays_o), f32c(rays_d)
     n = ro.numel() // 3

@@ -3,10 +3,10 @@
 the fused HIP kernel for device tensors; the other classes are kept as plain modules for name
 compatibility (out of the HIP scope)."""
 import torch
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_post_step
 
 from . import _ops
 
-
 _optimizer_steps = [0]   # bumped by a global optimizer post-step hook (see FlexibleNeRFModel.packed)
 
 
@@ -14,19 +14,11 @@ def _count_optimizer_step(*_args, **_kwargs):
     _optimizer_steps[0] += 1
 
 
-from torch.optim.optimizer import register_optimizer_step_post_hook as _register_post_step  # noqa: E402
-
-_register_post_step(_count_optimizer_step)
-
-
-_optimizer_steps = [0]   # bumped by a global optimizer post-step hook (see FlexibleNeRFModel.packed)
-
-
-def _count_optimizer_step(*_args, **_kwargs):
+def mark_parameters_updated():
+    """Tell the packed-weights caches that parameters changed behind PyTorch's back - e.g. after replaying a captured
+    HIP graph that contains an optimizer step (no Python hook runs during a replay)."""
     _optimizer_steps[0] += 1
 
-
-from torch.optim.optimizer import register_optimizer_step_post_hook as _register_post_step  # noqa: E402
 
 _register_post_step(_count_optimizer_step)
 

@@ -141,6 +141,39 @@ class RaySelector:
                                 pixel_index, image)
 
 
+class MultiViewRaySelector:
+    """RaySelector for a set of training cameras whose index is a DEVICE scalar: the camera records (two host inverses per
+    view, once) and the stacked images live on the device, so `select` contains no per-view host constant and a captured
+    HIP graph of the whole training iteration can be replayed for any view (`view.fill_(k)` before the replay)."""
+
+    def __init__(self, height, width, extrinsics, intrinsics, near, far, images=None, device=None):
+        self.height, self.width = int(height), int(width)
+        self.near, self.far = float(near), float(far)
+        self.device = torch.device(device) if device is not None else extrinsics[0].device
+        recs = []
+        for k, e in enumerate(extrinsics):
+            host = e.detach().to("cpu", torch.float32)
+            kmat = (intrinsics[k] if (torch.is_tensor(intrinsics) and intrinsics.dim() == 3) or isinstance(intrinsics, (list, tuple))
+                    else intrinsics).detach().to("cpu", torch.float32)
+            rec = torch.zeros(16)
+            rec[:9] = torch.inverse(host[:3, :3]).reshape(-1)
+            rec[9:12] = torch.inverse(host)[:3, -1]
+            rec[12], rec[13], rec[14] = kmat[0, 0], kmat[0, 2], kmat[1, 2]
+            recs.append(rec)
+        self.cams = torch.stack(recs).to(self.device).contiguous()
+        self.images = None if images is None else images.to(self.device, torch.float32).contiguous()   # (V, H, W, C)
+        self.view = torch.zeros((), dtype=torch.int32, device=self.device)
+
+    def random_pixels(self, n, generator=None):
+        total = self.height * self.width
+        return torch.randperm(total, device=self.device, generator=generator)[:min(n, total)]
+
+    def select(self, pixel_index, view=None):
+        """Rows + target pixels for the view held in `view` (default: self.view, set with `self.view.fill_(k)`)."""
+        return _ops.select_rays_indirect(self.height, self.width, self.cams, self.view if view is None else view, self.near,
+                                         self.far, pixel_index, self.images)
+
+
 def get_embedding_function(num_encoding_functions=6, include_input=True, log_sampling=True):
     """Reference nerf_helpers.py:162-169."""
     return Embedder(num_encoding_functions, include_input, log_sampling)

@@ -87,6 +87,9 @@ def main(argv=None):
     ap.add_argument("--save", default="", help="checkpoint path (reference dict format)")
     ap.add_argument("--load-checkpoint", default="")
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--no-hip-graph", action="store_true",
+                    help="launch every kernel of an iteration from Python instead of replaying one captured HIP graph "
+                         "(single-GPU runs capture by default: the as-shipped 4x128 nets at 1024 rays are launch-bound)")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,25 +127,29 @@ def main(argv=None):
     parallel.broadcast_parameters(student)
     torch.manual_seed(args.seed + 1000 + rank)
     bucket = parallel.FlatGradBucket(student)
-    opt = torch.optim.Adam(bucket.params, lr=args.lr, fused=True)
+    use_graph = (world == 1) and not args.no_hip_graph
+    lr_t = torch.tensor(args.lr, dtype=torch.float32, device=dev)   # a device scalar: the schedule is applied by fill_()
+    opt = torch.optim.Adam(bucket.params, lr=lr_t, fused=True, capturable=True)
     start = 0
     if args.load_checkpoint:
         ck = torch.load(args.load_checkpoint, map_location=dev)
         student[0].load_state_dict(ck["model_coarse_state_dict"])
         student[1].load_state_dict(ck["model_fine_state_dict"])
         opt.load_state_dict(ck["optimizer_state_dict"])
+        for group in opt.param_groups:
+            group["lr"] = lr_t
         start = ck["iter"]
     train_ids = list(range(args.views))[rank::world] or [rank % args.views]
-    # one selector per training camera: matrix inverses once, then a single kernel per step from pixel draws to packed
-    # ray rows + target pixels (reference: full-image bundle + coordinate grid + three gathers + normalise + cat)
-    selectors = {v: nerf.RaySelector(args.size, args.size, poses[v], k_mat, 2.0, 6.0, device=dev) for v in train_ids}
-    history = []
-    t0 = time.perf_counter()
-    loss_val = psnr = float("nan")
-    for it in range(start, args.iters):
-        view = int(np.random.choice(train_ids))
-        pix = selectors[view].random_pixels(args.num_random_rays)
-        rays, target = selectors[view].select(pix, images[view].reshape(args.size, args.size, 3))
+    # All training cameras + images live on the device and the view is a device scalar: from pixel draws to packed ray rows
+    # + target pixels is ONE kernel with no per-view host constant (reference: full-image bundle + coordinate grid + three
+    # gathers + normalise + cat per step), so the whole iteration can be captured once and replayed for any view.
+    selector = nerf.MultiViewRaySelector(args.size, args.size, [poses[v] for v in train_ids], k_mat, 2.0, 6.0,
+                                         images=torch.stack([images[v].reshape(args.size, args.size, 3) for v in train_ids]), device=dev)
+    loss_t = torch.zeros((), dtype=torch.float32, device=dev)
+
+    def iteration():
+        """select rays -> coarse + fine render -> loss -> backward -> (all-reduce) -> Adam; device-side state only."""
+        rays, target = selector.select(selector.random_pixels(args.num_random_rays))
         chunks = [nerf.predict_and_render_radiance(batch, student[0], student[1], cfg, mode="train", encode_position_fn=ex,
                                                    encode_direction_fn=ed, m_thres_cand=thres)
                   for batch in nerf.get_minibatches(rays, chunksize=args.chunksize)]
@@ -156,11 +163,38 @@ def main(argv=None):
         loss.backward()
         bucket.all_reduce_mean()              # one flat all-reduce (RCCL over xGMI when world > 1)
         opt.step()
-        lr = args.lr * args.lr_decay_factor ** (it / (args.lr_decay * 1000))   # train_dexnerf_rgb.py:284-289
-        for group in opt.param_groups:
-            group["lr"] = lr
+        loss_t.copy_(loss.detach())
+
+    graph = None
+    history = []
+    t0 = time.perf_counter()
+    loss_val = psnr = float("nan")
+    for it in range(start, args.iters):
+        selector.view.fill_(int(np.random.randint(len(train_ids))))                 # one random training view per iteration
+        lr = args.lr * args.lr_decay_factor ** (it / (args.lr_decay * 1000))         # train_dexnerf_rgb.py:284-289
+        lr_t.fill_(lr)
+        if use_graph and graph is None and it >= start + 3:
+            # three eager iterations have initialised every lazy state (optimizer moments, packed streams); capture the
+            # fourth and replay it from here on.  Anything that cannot be captured falls back to eager launches.
+            try:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    iteration()
+                nerf.models.mark_parameters_updated()
+            except Exception as exc:  # noqa: BLE001
+                graph, use_graph = None, False
+                torch.cuda.synchronize()
+                if rank == 0 and not args.quiet:
+                    print(f"[train] HIP-graph capture unavailable ({type(exc).__name__}: {exc}); launching eagerly", flush=True)
+                iteration()
+        elif graph is not None:
+            graph.replay()
+            nerf.models.mark_parameters_updated()   # the replayed optimizer step ran no Python hook
+        else:
+            iteration()
         if it % 100 == 0 or it == args.iters - 1:
-            loss_val = loss.item()
+            loss_val = loss_t.item()
             psnr = nerf.mse2psnr(loss_val)
             history.append((it, loss_val, psnr))
             if rank == 0 and not args.quiet:

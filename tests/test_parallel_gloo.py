@@ -57,17 +57,19 @@ def _case_flat_bucket(rank, world, tmp):
     parallel.broadcast_parameters([coarse, fine], src=0)
     bucket = parallel.FlatGradBucket([coarse, fine])
     n_params = sum(p.numel() for m in (coarse, fine) for p in m.parameters())
-    assert bucket.flat.numel() == n_params
     opt = torch.optim.Adam(bucket.params, lr=1e-2)
     torch.manual_seed(7 + rank)  # each rank: its own rays
     for step in range(3):
         x = torch.randn(16, coarse.dim_xyz + coarse.dim_dir)
         bucket.zero()
+        assert all(p.grad is None for p in bucket.params)      # autograd will assign, not accumulate
         loss = coarse(x).pow(2).mean() + fine(x).pow(2).mean()
         loss.backward()
-        assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in bucket.params)  # grads still views of the bucket
-        local = bucket.flat.clone()
+        local = torch.cat([p.grad.reshape(-1) for p in bucket.params]).clone()
         bucket.all_reduce_mean()
+        assert bucket.flat.numel() == n_params
+        lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + 4 * n_params
+        assert all(lo <= p.grad.data_ptr() < hi for p in bucket.params)   # every grad is now a view of the reduced buffer
         gathered = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(gathered, local)
         assert torch.allclose(bucket.flat, sum(gathered) / world, atol=1e-7)

@@ -471,12 +471,17 @@ struct WgParams {
 
 constexpr int kWgLdsBytes = 144 * 1024;
 
+// Tiles consumed per barrier: a small tile (few pieces) is a few MFMAs per wave, so the barrier + wait + LDS latency of
+// an iteration is amortised over 2 or 4 of them (the as-shipped 4x128 nets are all "small").
+constexpr int wg_tiles_per_iter(int pieces) { return pieces <= 12 ? 4 : (pieces <= 24 ? 2 : 1); }
+
 constexpr int wg_stages_for(int pieces) {
+  const int tpi = wg_tiles_per_iter(pieces);
   int s = kWgLdsBytes / (pieces * kPieceBytes);
   if (s > 16) s = 16;
   const int per_wave = (pieces + 7) / 8;
-  while (s > 2 && (s - 2) * per_wave > 48) --s;  // counted-wait range
-  return s < 2 ? 2 : s;
+  while (s > 2 * tpi && (s - 2 * tpi) * per_wave > 48) --s;  // counted-wait range
+  return s < 2 * tpi ? 2 * tpi : s;
 }
 
 // NTN: 32-row tiles of the output (dY) width; XT: 32-column tiles of the hidden input; PET: 32-column tiles of the
@@ -492,7 +497,9 @@ struct WgShape {
   static constexpr int N_X = 2 * XT, N_PE = 2 * PET;
   static constexpr int PIECES = N_DY + N_X + N_PE;         // 1 KiB pieces staged per 32-point tile
   static constexpr int PER_WAVE = (PIECES + 7) / 8;        // DMAs per tile of the busiest wave
-  static constexpr int STAGES = wg_stages_for(PIECES);
+  static constexpr int TPI = wg_tiles_per_iter(PIECES);     // tiles per barrier
+  static constexpr int STAGES = wg_stages_for(PIECES);      // tile buffers in LDS; STAGES - TPI tiles in flight
+  static_assert(STAGES >= 2 * TPI && STAGES * PIECES * kPieceBytes <= 160 * 1024, "LDS budget");
   static_assert(XT + PET >= 1 && NTN * KGROUPS == 8, "shape");
 };
 
@@ -587,11 +594,12 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
 #endif
     });
   };
-  // this wave issues PER_WAVE or PER_WAVE-1 DMAs per tile; STAGES-2 younger tiles may stay in flight (in-order retirement)
+  // this wave issues PER_WAVE or PER_WAVE-1 DMAs per tile; while TPI tiles are consumed, STAGES - 2*TPI younger tiles may
+  // stay in flight (in-order retirement)
   const bool full = (wave + 8 * (S::PER_WAVE - 1)) < S::PIECES;
-  auto wait_tile = [&]() {
-    if (full) wait_vmcnt<(S::STAGES - 2) * S::PER_WAVE>();
-    else wait_vmcnt<(S::STAGES - 2) * (S::PER_WAVE - 1)>();
+  auto wait_tiles = [&]() {
+    if (full) wait_vmcnt<(S::STAGES - 2 * S::TPI) * S::PER_WAVE>();
+    else wait_vmcnt<(S::STAGES - 2 * S::TPI) * (S::PER_WAVE - 1)>();
   };
 
   f32x16 acc[S::J];
@@ -603,23 +611,9 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
 #pragma unroll
   for (int e = 0; e < 8; ++e) { ones[e] = static_cast<__bf16>(1.0f); zeros[e] = static_cast<__bf16>(0.0f); }
 
-  long long tile = wg;
-  int buf = 0;
-#pragma unroll 1
-  for (int st = 0; st + 1 < S::STAGES; ++st) stage(tile + static_cast<long long>(st) * n_wg, st);
-#pragma unroll 1
-  for (; tile < tiles; tile += n_wg) {
-    // this wave's DMAs of tile `tile` are done, and so are its LDS reads of the previous tile ...
-    wait_tile();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // ... after the barrier everyone's are: the tile is resident and the previous tile's buffer is free
-    __builtin_amdgcn_s_barrier();
-    {
-      int nb = buf + S::STAGES - 1;
-      if (nb >= S::STAGES) nb -= S::STAGES;
-      stage(tile + static_cast<long long>(S::STAGES - 1) * n_wg, nb);
-    }
-    const char* base = smem + buf * BUF + lane_off;
+  // one staged tile: A = dY^T fragments of this wave's n-tile, B = the X / PE / all-ones k-tiles, 2 MFMAs per k-tile
+  auto consume = [&](long long tile, int cb) {
+    const char* base = smem + cb * BUF + lane_off;
     // A = dY^T fragments of this wave's n-tile, two 16-point k-steps
     // (a custom dY has a single piece: the fs=1 lane groups re-read it and are zeroed)
     const int dy_piece = S::CUSTOM ? 0 : 2 * ntile + fs;
@@ -664,7 +658,54 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
     });
-    buf = (buf + 1 == S::STAGES) ? 0 : buf + 1;
+  };
+  // tile k of this workgroup's sequence (k = 0, 1, ...) is 32-point tile wg + k * n_wg and lives in buffer k % STAGES
+  int buf = 0;
+  if constexpr (S::TPI == 1) {
+    // one tile per barrier (the big shapes: their accumulators leave no register to spare - keep this loop minimal)
+    long long tile = wg;
+#pragma unroll 1
+    for (int st = 0; st + 1 < S::STAGES; ++st) stage(tile + static_cast<long long>(st) * n_wg, st);
+#pragma unroll 1
+    for (; tile < tiles; tile += n_wg) {
+      // this wave's DMAs of tile `tile` are done, and so are its LDS reads of the previous tile ...
+      wait_tiles();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // ... after the barrier everyone's are: the tile is resident and the previous tile's buffer is free
+      __builtin_amdgcn_s_barrier();
+      {
+        int nb = buf + S::STAGES - 1;
+        if (nb >= S::STAGES) nb -= S::STAGES;
+        stage(tile + static_cast<long long>(S::STAGES - 1) * n_wg, nb);
+      }
+      consume(tile, buf);
+      buf = (buf + 1 == S::STAGES) ? 0 : buf + 1;
+    }
+  } else {
+    // TPI tiles per barrier (small shapes: a tile is a few MFMAs per wave, the barrier + wait + LDS latency dominate)
+    auto tile_of = [&](long long k) { return wg + k * n_wg; };
+#pragma unroll 1
+    for (int st = 0; st < S::STAGES - S::TPI; ++st) stage(tile_of(st), st);
+#pragma unroll 1
+    for (long long k0 = 0; tile_of(k0) < tiles; k0 += S::TPI) {
+      wait_tiles();   // tiles k0 .. k0+TPI-1 landed; STAGES - 2*TPI younger ones may be in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int t = 0; t < S::TPI; ++t) {
+        int nb = buf + S::STAGES - S::TPI + t;
+        if (nb >= S::STAGES) nb -= S::STAGES;
+        stage(tile_of(k0 + S::STAGES - S::TPI + t), nb);
+      }
+      static_for<S::TPI>([&](auto t_c) {
+        constexpr int tsub = decltype(t_c)::value;
+        int cb = buf + tsub;
+        if (cb >= S::STAGES) cb -= S::STAGES;
+        if (tile_of(k0 + tsub) < tiles) consume(tile_of(k0 + tsub), cb);
+      });
+      buf += S::TPI;
+      if (buf >= S::STAGES) buf -= S::STAGES;
+    }
   }
   wait_vmcnt<0>();  // the trailing re-loads
   // ---- add this workgroup's partial: D[i][j] sits in lane (j = lane&31, half = lane>>5), register r, i = acc_row(r, half)
@@ -726,7 +767,11 @@ static int wg_shape_lds(int shape) {
 
 __device__ __forceinline__ void weight_grad_dispatch(const WgParams& p, int wg, int n_wg, char* smem) {
   switch (p.shape) {  // workgroup-uniform
+#ifdef DN_WG_ONLY   // developer hook: compile a single shape (register-pressure bisection)
+#define X(id, a, b, c, d) case id: if constexpr (id == DN_WG_ONLY) weight_grad_unit<WgShape<a, b, c, d>>(p, wg, n_wg, smem); break;
+#else
 #define X(id, a, b, c, d) case id: weight_grad_unit<WgShape<a, b, c, d>>(p, wg, n_wg, smem); break;
+#endif
     DN_WG_SHAPES(X)
 #undef X
     default: break;

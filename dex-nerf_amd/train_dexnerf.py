@@ -34,7 +34,7 @@ def make_cfg(args):
     def mode(train):
         return dict(chunksize=args.chunksize, lindisp=False, num_coarse=args.num_coarse, num_fine=args.num_fine,
                     perturb=train, radiance_field_noise_std=args.noise_std if train else 0.0, white_background=False)
-    return nerf.CfgNode(dict(dataset=dict(near=2.0, far=6.0, no_ndc=True),
+    return nerf.CfgNode(dict(dataset=dict(near=args.near, far=args.far, no_ndc=True),
                              nerf=dict(use_viewdirs=True, train=mode(True), validation=mode(False))))
 
 
@@ -48,19 +48,50 @@ def build_models(kw, dev, state=None):
     return out
 
 
-def render_view(models, cfg, pose, k_mat, size, ex, ed, thres, mode="validation"):
-    ro, rd = nerf.get_ray_bundle(size, size, float(k_mat[0, 0]), pose, k_mat)
+def render_view(models, cfg, pose, k_mat, hw, ex, ed, thres, mode="validation"):
+    h, w = hw
+    ro, rd = nerf.get_ray_bundle(h, w, float(k_mat[0, 0]), pose, k_mat)
     with torch.no_grad():
-        return nerf.run_one_iter_of_nerf(size, size, float(k_mat[0, 0]), models[0], models[1], ro, rd, cfg, mode=mode,
+        return nerf.run_one_iter_of_nerf(h, w, float(k_mat[0, 0]), models[0], models[1], ro, rd, cfg, mode=mode,
                                          encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=thres)
 
 
-def dex_sweep(outputs, depth_gt, thres):
+def dex_sweep(outputs, depth_gt, thres, gt_hi=6.0):
     """Pick the Dex threshold with the smallest mean |depth error| (reference train_dexnerf_rgb.py:391-408): all
-    candidates in one kernel + one copy (nerf.dex_error_sweep); the synthetic scene spans (0, 6) m."""
-    best, errs = nerf.dex_error_sweep(depth_gt, list(outputs[6:]), gt_lo=0.0, gt_hi=6.0)
+    candidates in one kernel + one copy (nerf.dex_error_sweep).  Ground mask 0 < gt < gt_hi (the reference: 1.25 m for
+    its table-top scenes; the built-in synthetic scene spans (0, 6) m)."""
+    best, errs = nerf.dex_error_sweep(depth_gt, list(outputs[6:]), gt_lo=0.0, gt_hi=gt_hi)
     best = int(np.argmin([e["depth_abs_err"] for e in errs])) if best is None else best
     return thres[best], errs[best]
+
+
+def synthetic_dataset(args, kw, cfg, ex, ed, thres, dev):
+    """No dataset ships with the reference: a fixed random coarse/fine FlexibleNeRFModel pair ("teacher") is rendered from
+    `views` + 1 spherical poses; the last pose is held out."""
+    hw = (args.size, args.size)
+    k_mat = torch.from_numpy(syn.intrinsic(*hw)).to(dev)
+    poses = [torch.from_numpy(syn.scene_pose(i, n_views=args.views + 1)).to(dev) for i in range(args.views + 1)]
+    teacher = build_models(kw, dev, (syn.synth_state_dict(42, sigma_bias=-150.0, **kw), syn.synth_state_dict(43, sigma_bias=-20.0, **kw)))
+    images, depths = [], []
+    for pose in poses:
+        out = render_view(teacher, cfg, pose, k_mat, hw, ex, ed, thres)
+        images.append(out[3].reshape(-1, 3))
+        depths.append(out[4].reshape(hw))
+    return dict(hw=hw, poses=poses, intrinsics=[k_mat] * len(poses), images=images, depths=depths,
+                train=list(range(args.views)), val=args.views, mask_hi=6.0)
+
+
+def messytable_dataset(args, dev):
+    """A scene directory in the reference's MessyTable / Dex-NeRF layout (nerf/load_messytable.py; `half_res` = the
+    fork's 270 x 480 training resolution with the principal point pinned to (240, 135))."""
+    imgs, poses, _, hwf, i_split, intrinsics, depths = nerf.load_messytable_data(
+        args.messytable, half_res=True, imgname=args.imgname, is_real_rgb=args.real_rgb)
+    hw = (int(hwf[0]), int(hwf[1]))
+    n = imgs.shape[0]
+    val = int(i_split[1][0]) if len(i_split[1]) else int(i_split[0][-1])
+    return dict(hw=hw, poses=[poses[i].to(dev) for i in range(n)], intrinsics=[intrinsics[i].to(dev) for i in range(n)],
+                images=[imgs[i, ..., :3].reshape(-1, 3).to(dev) for i in range(n)], depths=[depths[i].to(dev) for i in range(n)],
+                train=[int(i) for i in i_split[0]], val=val, mask_hi=1.25)
 
 
 def main(argv=None):
@@ -86,11 +117,21 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--save", default="", help="checkpoint path (reference dict format)")
     ap.add_argument("--load-checkpoint", default="")
+    ap.add_argument("--messytable", default="", help="train on a scene directory in the reference's MessyTable / Dex-NeRF "
+                                                     "layout instead of the built-in synthetic scene")
+    ap.add_argument("--imgname", default="0128_irL_kuafu_half.png")
+    ap.add_argument("--real-rgb", action="store_true")
+    ap.add_argument("--near", type=float, default=None, help="default 2 (synthetic scene) / 0.3 (MessyTable)")
+    ap.add_argument("--far", type=float, default=None, help="default 6 (synthetic scene) / 4 (MessyTable)")
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--no-hip-graph", action="store_true",
                     help="launch every kernel of an iteration from Python instead of replaying one captured HIP graph "
                          "(single-GPU runs capture by default: the as-shipped 4x128 nets at 1024 rays are launch-bound)")
     args = ap.parse_args(argv)
+    if args.near is None:
+        args.near = 0.3 if args.messytable else 2.0
+    if args.far is None:
+        args.far = 4.0 if args.messytable else 6.0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -110,17 +151,9 @@ def main(argv=None):
     cfg = make_cfg(args)
     ex, ed = nerf.get_embedding_function(10, True, True), nerf.get_embedding_function(4, True, True)
     thres = np.arange(5, args.m_thres + 5, 5)
-    k_mat = torch.from_numpy(syn.intrinsic(args.size, args.size)).to(dev)
-    poses = [torch.from_numpy(syn.scene_pose(i, n_views=args.views + 1)).to(dev) for i in range(args.views + 1)]
-
-    # ---- synthetic dataset: a fixed teacher field rendered from every pose (last pose is held out) ----
-    teacher = build_models(kw, dev, (syn.synth_state_dict(42, sigma_bias=-150.0, **kw), syn.synth_state_dict(43, sigma_bias=-20.0, **kw)))
-    images, depths = [], []
-    for pose in poses:
-        out = render_view(teacher, cfg, pose, k_mat, args.size, ex, ed, thres)
-        images.append(out[3].reshape(-1, 3))
-        depths.append(out[4].reshape(args.size, args.size))
-    del teacher
+    data = messytable_dataset(args, dev) if args.messytable else synthetic_dataset(args, kw, cfg, ex, ed, thres, dev)
+    hw, poses, intrinsics, images, depths = data["hw"], data["poses"], data["intrinsics"], data["images"], data["depths"]
+    held_out = data["val"]
 
     torch.manual_seed(args.seed)              # identical student init on every rank
     student = build_models(kw, dev)
@@ -139,12 +172,13 @@ def main(argv=None):
         for group in opt.param_groups:
             group["lr"] = lr_t
         start = ck["iter"]
-    train_ids = list(range(args.views))[rank::world] or [rank % args.views]
+    train_ids = data["train"][rank::world] or [data["train"][rank % len(data["train"])]]
     # All training cameras + images live on the device and the view is a device scalar: from pixel draws to packed ray rows
     # + target pixels is ONE kernel with no per-view host constant (reference: full-image bundle + coordinate grid + three
     # gathers + normalise + cat per step), so the whole iteration can be captured once and replayed for any view.
-    selector = nerf.MultiViewRaySelector(args.size, args.size, [poses[v] for v in train_ids], k_mat, 2.0, 6.0,
-                                         images=torch.stack([images[v].reshape(args.size, args.size, 3) for v in train_ids]), device=dev)
+    selector = nerf.MultiViewRaySelector(hw[0], hw[1], [poses[v] for v in train_ids], [intrinsics[v] for v in train_ids],
+                                         args.near, args.far,
+                                         images=torch.stack([images[v].reshape(hw[0], hw[1], 3) for v in train_ids]), device=dev)
     loss_t = torch.zeros((), dtype=torch.float32, device=dev)
 
     def iteration():
@@ -201,9 +235,9 @@ def main(argv=None):
                 print(f"[train] iter {it:6d} loss {loss_val:.5f} psnr {psnr:.2f} dB lr {lr:.2e} "
                       f"{(time.perf_counter() - t0):.1f} s", flush=True)
         if rank == 0 and args.validate_every and (it + 1) % args.validate_every == 0:
-            out = render_view(student, cfg, poses[-1], k_mat, args.size, ex, ed, thres)
-            vmse = nerf.img2mse(out[3].reshape(-1, 3), images[-1]).item()
-            m_best, err = dex_sweep(out, depths[-1], thres)
+            out = render_view(student, cfg, poses[held_out], intrinsics[held_out], hw, ex, ed, thres)
+            vmse = nerf.img2mse(out[3].reshape(-1, 3), images[held_out]).item()
+            m_best, err = dex_sweep(out, depths[held_out], thres, data["mask_hi"])
             if not args.quiet:
                 print(f"[val]   iter {it + 1:6d} held-out view psnr {nerf.mse2psnr(vmse):.2f} dB; Dex best m={m_best} "
                       f"abs depth err {err['depth_abs_err']:.1f} mm", flush=True)
@@ -212,8 +246,10 @@ def main(argv=None):
     result = dict(history=history, final_loss=loss_val, final_psnr=psnr, seconds=elapsed,
                   rays_per_s=world * args.num_random_rays * (args.iters - start) / max(elapsed, 1e-9))
     if rank == 0:
-        out = render_view(student, cfg, poses[-1], k_mat, args.size, ex, ed, thres)
-        result["val_psnr"] = nerf.mse2psnr(nerf.img2mse(out[3].reshape(-1, 3), images[-1]).item())
+        out = render_view(student, cfg, poses[held_out], intrinsics[held_out], hw, ex, ed, thres)
+        result["val_psnr"] = nerf.mse2psnr(nerf.img2mse(out[3].reshape(-1, 3), images[held_out]).item())
+        m_best, err = dex_sweep(out, depths[held_out], thres, data["mask_hi"])
+        result["dex_best_threshold"], result["dex_abs_err_mm"] = int(m_best), err["depth_abs_err"]
         if args.save:
             torch.save({"iter": args.iters, "model_coarse_state_dict": student[0].state_dict(),
                         "model_fine_state_dict": student[1].state_dict(), "optimizer_state_dict": opt.state_dict(),

@@ -337,7 +337,7 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
       if (pt < p.n_points && h == 0) {
         f32x4 o;
         o[0] = out4[t][0]; o[1] = out4[t][1]; o[2] = out4[t][2]; o[3] = out4[t][3];
-        *reinterpret_cast<f32x4*>(p.out + pt * 4) = o;
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p.out + pt * 4));  // write-once stream: keep it out of the weight stream's L2
       }
     }
   }

@@ -175,3 +175,24 @@ def test_validation_helpers_host_path(golden):
     sel = nerf.RaySelector(30, 40, torch.from_numpy(g["sel_E"]), torch.from_numpy(g["sel_K"]), 2.0, 6.0, device="cpu")
     pix = sel.from_reference_choice(g["sel_inds"])
     np.testing.assert_array_equal(torch.from_numpy(g["sel_image"]).reshape(-1, 4)[pix].numpy(), g["sel_target"])
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The bench line committed under profiles/ (written by bench.py on an MI355X) carries every field the driver's
+    contract names, with the roofline and cpu_baseline objects."""
+    import json
+    path = os.path.join(REPO, "profiles", "r01_final_bench_bf16.json")
+    line = json.loads(open(path).read().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["unit"] == "rays/s" and line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert "workload" in line["config"] and "model" not in line["config"]
+    roof = line["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert roof["traffic"] is None or roof["traffic"] > 0
+    cb = line["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    # value = rays of all ranks / time: consistent with ms_per_step
+    rays = line["config"]["rays_per_step_per_gpu"] * line["n_gpus"]
+    assert abs(line["value"] - rays / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6

@@ -311,6 +311,7 @@ class VolumeRenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rf, z, rd, noise, noise_std, white, m_thres):
         rgb, disp, acc, weights, depth, dex = volume_render_fwd(rf, z, rd, noise, noise_std, white, m_thres)
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None (the kernel takes NULL), not as zero-filled tensors
         ctx.save_for_backward(rf, z, rd, noise if noise is not None else torch.empty(0, device=rf.device))
         ctx.cfg = (float(noise_std), bool(white), noise is not None)
         outs = (rgb, disp, acc, weights, depth) + ((dex,) if dex is not None else ())

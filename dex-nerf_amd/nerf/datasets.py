@@ -182,7 +182,7 @@ def save_ray_cache(path, height, width, focal_length, ray_origins, ray_direction
 
 def load_ray_cache(path, device=None):
     """Reads either dialect; returns (height, width, focal_length, ray_origins, ray_directions, target)."""
-    d = torch.load(path, map_location="cpu")
+    d = torch.load(path, map_location="cpu", weights_only=False)   # plain dicts written by save_ray_cache / cache_dataset.py (may hold numpy scalars)
     if "ray_bundle" in d:
         ro, rd = d["ray_bundle"][0], d["ray_bundle"][1]
     else:

@@ -139,3 +139,24 @@ def test_llff_loader_is_explicitly_absent():
     import nerf
     with pytest.raises(NotImplementedError):
         nerf.load_llff_data("/nonexistent")
+
+
+def test_cache_dataset_cli(tmp_path):
+    """The cache_dataset.py counterpart on a hand-built Blender scene: file names, dict dialects, ray subsets."""
+    import sys
+    import nerf
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dex-nerf_amd"))
+    import cache_dataset
+    src, dst = str(tmp_path / "scene"), str(tmp_path / "cache")
+    os.makedirs(src)
+    frames = _write_blender(src, n_frames=(2, 1, 1), size=16)
+    if torch.cuda.is_available():
+        pytest.skip("host-path test")
+    written = cache_dataset.main(["--datapath", src, "--savedir", dst, "--num-random-rays", "5", "--num-variations", "2"])
+    assert sorted(os.path.relpath(w, dst) for w in set(written)) == ["train/0000.data", "train/0001.data", "val/0002.data"]
+    h, w, focal, ro, rd, target = nerf.load_ray_cache(os.path.join(dst, "train", "0001.data"))
+    assert (h, w) == (4, 4) and ro.shape == (5, 3) and rd.shape == (5, 3) and target.shape == (5, 4)     # quarter res (fork quirk)
+    h, w, focal, ro, rd, target = nerf.load_ray_cache(os.path.join(dst, "val", "0002.data"))
+    assert ro.shape == (4, 4, 3) and target.shape == (4, 4, 4)
+    full, _, _, _, _ = nerf.load_blender_data(src, half_res=True)
+    assert torch.equal(target, full[2])

@@ -135,13 +135,16 @@ def main(argv=None):
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)   # (rehearsals: ranks may share a GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" is RCCL on ROCm; DEXNERF_DIST_BACKEND=gloo lets the data-parallel loop be rehearsed with several ranks on
+        # one GPU (RCCL refuses two ranks on the same device)
+        backend = os.environ.get("DEXNERF_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     np.random.seed(args.seed + rank)          # reference seeds np + torch from cfg.experiment.randomseed (:97-99)
     torch.manual_seed(args.seed + rank)
     nerf.set_precision(args.precision)
@@ -245,6 +248,8 @@ def main(argv=None):
     elapsed = time.perf_counter() - t0
     result = dict(history=history, final_loss=loss_val, final_psnr=psnr, seconds=elapsed,
                   rays_per_s=world * args.num_random_rays * (args.iters - start) / max(elapsed, 1e-9))
+    if args.save and rank != 0 and os.environ.get("DEXNERF_SAVE_ALL_RANKS"):   # rehearsals: compare the replicas
+        torch.save({"model_coarse_state_dict": student[0].state_dict(), "model_fine_state_dict": student[1].state_dict()}, args.save)
     if rank == 0:
         out = render_view(student, cfg, poses[held_out], intrinsics[held_out], hw, ex, ed, thres)
         result["val_psnr"] = nerf.mse2psnr(nerf.img2mse(out[3].reshape(-1, 3), images[held_out]).item())

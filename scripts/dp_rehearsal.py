@@ -1,0 +1,12 @@
+"""Developer helper: one rank of a data-parallel rehearsal of train_dexnerf.py (launch with torch.distributed.run and
+DEXNERF_DIST_BACKEND=gloo to put several ranks on one GPU)."""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "dex-nerf_amd"))
+import train_dexnerf
+args = ["--iters", "150", "--size", "32", "--views", "6", "--num-random-rays", "512", "--layers", "4", "--width", "128",
+        "--validate-every", "0", "--quiet", "--precision", "bf16"]
+args += ["--save", os.path.join(os.environ.get("CKDIR", "/tmp"), f"dp_rank{os.environ.get('RANK', '0')}.ckpt")]
+os.environ["DEXNERF_SAVE_ALL_RANKS"] = "1"
+res = train_dexnerf.main(args)
+print("RESULT", os.environ.get("RANK", "0"), res["history"][0][2], res["history"][-1][2], flush=True)

@@ -183,12 +183,16 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
     auto save_piece = [&](int t, int slot, const BPiece& v) {
       store16_uniform(act_tile[t] + static_cast<long long>(slot) * kPieceBytes, pipe.lane16, v);
     };
-    auto save_pieces = [&](auto nt_c, int t, int slot0, const BPiece* pieces) {
+    // (the piece arrays are passed by reference to their array type and indexed with compile-time constants only: a
+    // decayed pointer sends the whole register-resident activation set to scratch memory in the fp32 instances)
+    auto save_pieces = [&](auto nt_c, int t, int slot0, const auto& pieces) {
 #ifndef DN_EXP_NOSAVE
       if constexpr (SAVE) {
         constexpr int nt = decltype(nt_c)::value;
-#pragma unroll
-        for (int s2 = 0; s2 < P::PPT; ++s2) save_piece(t, slot0 + nt * P::PPT + s2, pieces[nt * P::PPT + s2]);
+        static_for<P::PPT>([&](auto s_c) {
+          constexpr int s2 = decltype(s_c)::value;
+          save_piece(t, slot0 + nt * P::PPT + s2, pieces[nt * P::PPT + s2]);
+        });
       }
 #endif
     };
@@ -200,19 +204,19 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
     // ReLU mask bits of output tile nt (layout: relu_mask_bit).  16-bit modes read them off the packed ReLU outputs
     // (non-zero <=> pre-activation > 0 in the arithmetic the kernel actually ran): one v_pk_min_u16 + one shift-or per
     // dword instead of compare + select + or per element with sixteen bit constants held in VGPRs.
-    auto mask_tile = [&](auto nt_c, int t, const f32x16& acc, const BPiece* pieces) {
+    auto mask_tile = [&](auto nt_c, int t, const f32x16& acc, const auto& pieces) {
       if constexpr (SAVE) {
         constexpr int nt = decltype(nt_c)::value;
         if constexpr (BF16) {
           typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
           const u16x8 one = {1, 1, 1, 1, 1, 1, 1, 1};
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
+          static_for<2>([&](auto s_c) {
+            constexpr int s2 = decltype(s_c)::value;
             const u32x4 m = __builtin_bit_cast(u32x4, __builtin_elementwise_min(__builtin_bit_cast(u16x8, pieces[nt * 2 + s2]), one));
 #pragma unroll
             for (int d = 0; d < 4; ++d) maskw[t][nt / 2] |= m[d] << (s2 * 4 + d + 8 * (nt & 1));
-          }
+          });
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
@@ -246,7 +250,9 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
     BPiece none[PT][1];
     int bias_tile = 0;
     // One trunk layer: layers_xyz[i] on (cat(x, xyz) when it is a skip layer) -> W, ReLU (models.py:239-246)
-    auto trunk_layer = [&](int i, const BPiece (&bin)[PT][KH], BPiece (&bout)[PT][KH]) {
+    // always_inline: left as a call (hipcc does that for the large fp32 instances) the register-resident activation sets
+    // would have to live in scratch memory to be passed by reference
+    auto trunk_layer = [&](int i, const BPiece (&bin)[PT][KH], BPiece (&bout)[PT][KH]) __attribute__((always_inline)) {
       auto emit = [&](auto nt_c, auto t_c, const f32x16& acc) {
         constexpr int t = decltype(t_c)::value;
         emit_pieces<BF16, true, decltype(nt_c)::value>(acc, bout[t]);

@@ -222,7 +222,7 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
     constexpr int PN = NT % kPhasePieces;                                            // fc_out head
     auto trunk = [&](auto pos_c) {
       constexpr int POS = decltype(pos_c)::value;
-      auto layer = [&](int i, const BPiece (&bin)[PT][KH], BPiece (&bout)[PT][KH]) {
+      auto layer = [&](int i, const BPiece (&bin)[PT][KH], BPiece (&bout)[PT][KH]) __attribute__((always_inline)) {
         const uint4 mw = stage_begin(q++);
         const int gslot = i > 0 ? p.gslot_trunk0 + (i - 1) * KH : p.gslot_layer1;
         run_stage<BF16, PT, NT, KH, 0, POS, false>(pipe, bin, no_pe, nullptr, [&](auto nt_c, auto, const f32x16& acc) {

@@ -276,6 +276,20 @@ def main():
             nerf.set_precision(args.precision)
         if not args.no_train and world == 1:
             result["train"] = train_rate(models, cfg, ro, rd, ex, ed)
+        if not args.no_train and world == 1 and args.precision == "bf16":
+            # BASELINE config 3 as a shape: the as-shipped 4 x 128 nets, 1024 rays per step, 64+64 samples, whole iteration
+            # replayed as one HIP graph by the build-owned driver (informational; a few seconds)
+            try:
+                sys.path.insert(0, os.path.join(REPO, "dex-nerf_amd"))
+                import train_dexnerf
+                res = train_dexnerf.main(["--iters", "4000", "--size", "64", "--views", "8", "--num-random-rays", "1024", "--layers", "4",
+                                          "--width", "128", "--num-fine", "64", "--validate-every", "0", "--quiet", "--precision", "bf16"])
+                result["train_as_shipped"] = {"rays_per_s": res["rays_per_s"], "rays_per_step": 1024,
+                                              "what": "train_dexnerf.py, 4x128 nets, 64+64 samples, HIP-graph replay, incl. capture time"}
+            except Exception as exc:  # noqa: BLE001
+                result["train_as_shipped"] = {"error": f"{type(exc).__name__}: {exc}"}
+            finally:
+                nerf.set_precision(args.precision)
         result["roofline"]["library_gemm"] = library_gemm_tflops(dev, args.precision)
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -1,10 +1,10 @@
 """training PSNR at matched iteration counts, HIP kernels vs the CPU oracle.
 Both learn the same synthetic teacher images (rendered once by the HIP path) from the same initial weights with the same
 loss / optimizer / schedule; the ray draws come from each side's own generator, so the comparison is statistical.
-Test infrastructure (uses oracle/): a developer script, like bench.py's cpu_baseline leg - never part of the product path."""
+Lives under tests/ because it uses oracle/ (test infrastructure): the product package never does."""
 import os, sys, time
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "dex-nerf_amd"))
 import nerf
 from nerf import synthetic as syn

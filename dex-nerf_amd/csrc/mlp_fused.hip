@@ -8,13 +8,15 @@
 //     (rows = features, column = lane = point) is fed back as the B operand of layer l+1, so no
 //     activation ever touches LDS or HBM;
 //   * weights arrive as a linear stream of 1 KiB MFMA-A pieces, LDS-DMA'd (global_load_lds_dwordx4) from
-//     L2 into a 4-slot x 16 KiB LDS ring shared by the waves of the workgroup; one counted
-//     `s_waitcnt vmcnt(N)` + one raw `s_barrier` per 16 pieces, three phases of prefetch always in flight;
+//     L2 into a 5-slot x 16 KiB LDS ring shared by the waves of the workgroup; one counted
+//     `s_waitcnt vmcnt(N)` + one raw `s_barrier` per 16 pieces; the next phase is always fully landed, two more are
+//     in flight;
 //   * positional encodings are computed in registers straight into B-fragment layout (the reference
 //     materialises a (P,90) tensor and recomputes the direction encoding per sample);
-//   * bf16 mode: v_mfma_f32_32x32x16_bf16, 8 waves x 32 points per workgroup, 2 waves / SIMD;
+//   * bf16 / fp16 modes: v_mfma_f32_32x32x16_{bf16,f16}, 8 waves x 32 points per workgroup, 2 waves / SIMD;
 //     fp32 mode: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), 4 waves x 32 points, 1 wave / SIMD.
-// MFMA-bound: 1,186,816 FLOP per point (D8/W256) against 16 B written per point.
+// MFMA-bound: 1,186,816 FLOP per point (D8/W256) against 16 B written per point.  SAVE = the training forward: the same
+// chain also streams every stage's output pieces (non-temporal, scalar-base stores) and ReLU mask words to HBM.
 #include "mlp_device.h"
 #include "mlp_internal.h"
 

@@ -6,8 +6,9 @@
 //     dX^T[K x 32] = W^T[K x N] . dY^T[N x 32],   dY = dX_next (.) relu'(Y)
 // so the gradient tile produced by one stage's MFMAs is (after masking) the B operand of the next stage, exactly
 // like the activations in the forward.  Every masked gradient dL/d(pre-activation) is written out once in the
-// wave-native piece layout; dW/db are formed from those and the saved activations (dn_mlp_unpack + GEMM).
-// MFMA-bound like the forward: 2 x hidden MACs per point, 16-32 B/point/stage written.
+// wave-native piece layout; dW/db are formed from those and the saved activations by the weight-gradient kernel at
+// the end of this file (bf16), or by dn_mlp_unpack + library GEMMs (fp32 mode).
+// In practice bound by the HBM write stream of the stored gradients (3.6 KiB/point at D8/W256), not by the MFMAs.
 #include "mlp_internal.h"
 
 namespace dn {

@@ -7,7 +7,7 @@
 // so the gradient tile produced by one stage's MFMAs is (after masking) the B operand of the next stage, exactly
 // like the activations in the forward.  Every masked gradient dL/d(pre-activation) is written out once in the
 // wave-native piece layout; dW/db are formed from those and the saved activations by the weight-gradient kernel at
-// the end of this file (bf16), or by dn_mlp_unpack + library GEMMs (fp32 mode).
+// the end of this file (bf16 MFMA, or exact-fp32 MFMA in the parity mode).
 // In practice bound by the HBM write stream of the stored gradients (3.6 KiB/point at D8/W256), not by the MFMAs.
 #include "mlp_internal.h"
 
@@ -741,6 +741,174 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
   });
 }
 
+// ---- exact-fp32 variant (the parity mode) ---------------------------------------------------------------------
+// Same decomposition on the fp32 buffers (4 pieces of 64 lanes x 4 floats per 32-feature tile) with
+// v_mfma_f32_32x32x2_f32: every MFMA contracts TWO points, A lane (i, kk) = dY[point 2m+kk][feature i], B lane (j, kk) =
+// X[point 2m+kk][feature j], both fetched from the staged pieces with ds_read_b32 (gfx950's transposing reads stop at 16
+// bits).  Feature f of a tile sits in piece f/8, lane half (f%8)/4, element f%4 (acc_row), so the operand rows / columns
+// are the natural feature order.  Pieces are staged 1056 bytes apart: the 32-byte skew spreads the four pieces of a
+// tile over the LDS banks (bank = 8*piece + 4*kk + element: 32 distinct, 2-way on the lane half only).
+// MFMA-bound at the fp32 matrix rate (16 MFMAs of 64 cycles per tile pair per 32 points), two tile buffers in LDS.
+constexpr int kWg32PieceStride = kPieceBytes + 32;
+
+template <int NTN_, int XT_, int PET_, bool CUSTOM_>
+struct WgShape32 {
+  static constexpr int NTN = NTN_, XT = XT_, PET = PET_;
+  static constexpr bool CUSTOM = CUSTOM_;
+  static constexpr int KT = XT + PET + 1;
+  static constexpr int KGROUPS = 8 / NTN;
+  static constexpr int J = (KT + KGROUPS - 1) / KGROUPS;
+  static constexpr int N_DY = CUSTOM ? 1 : 4 * NTN;
+  static constexpr int N_X = 4 * XT, N_PE = 4 * PET;
+  static constexpr int PIECES = N_DY + N_X + N_PE;
+  static constexpr int PER_WAVE = (PIECES + 7) / 8;
+  static constexpr int BUF = PIECES * kWg32PieceStride;
+  static constexpr int STAGES = (kWgLdsBytes + 8 * 1024) / BUF >= 3 ? 3 : 2;   // 152 KiB budget; deeper does not fit the big shapes
+  static_assert(STAGES * BUF <= 158 * 1024 && (STAGES - 2) * PER_WAVE <= 48, "LDS / counted-wait budget");
+};
+
+template <class S>
+__device__ __forceinline__ void weight_grad_unit_f32(const WgParams& p, int wg, int n_wg, char* smem) {
+  const long long tiles = (p.n_points + 31) / 32;
+  if (wg >= tiles) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ntile = wave % S::NTN;
+  const int kgroup = wave / S::NTN;
+  const int i = lane & 31, kk = lane >> 5;                       // operand row / column and point parity of this lane
+  // byte offset of feature i's element inside a tile's 4-piece group, for point parity kk (point 2m+kk adds 32*m bytes)
+  const int feat_off = (i >> 3) * kWg32PieceStride + (((i & 7) >> 2) * 32 + kk) * 16 + (i & 3) * 4;
+  const unsigned lane16 = lane * 16;
+  const unsigned smem_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
+  const char* src0[S::PER_WAVE];
+  long long stride[S::PER_WAVE];
+  static_for<S::PER_WAVE>([&](auto e_c) {
+    constexpr int e = decltype(e_c)::value;
+    const int pi = wave + 8 * e;
+    if (pi < S::N_DY) { src0[e] = p.grads + static_cast<long long>(p.g_slot + pi) * kPieceBytes; stride[e] = static_cast<long long>(p.grad_pieces) * kPieceBytes; }
+    else if (pi < S::N_DY + S::N_X) { src0[e] = p.act + static_cast<long long>(p.x_slot + pi - S::N_DY) * kPieceBytes; stride[e] = static_cast<long long>(p.act_pieces) * kPieceBytes; }
+    else { src0[e] = p.act + static_cast<long long>(p.pe_slot + pi - S::N_DY - S::N_X) * kPieceBytes; stride[e] = static_cast<long long>(p.act_pieces) * kPieceBytes; }
+  });
+  auto stage = [&](long long tile32, int buf) {
+    if (tile32 >= tiles) tile32 = tiles - 1;
+    static_for<S::PER_WAVE>([&](auto e_c) {
+      constexpr int e = decltype(e_c)::value;
+      const unsigned long long src_bits = reinterpret_cast<unsigned long long>(src0[e] + tile32 * stride[e]);
+      const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(src_bits));
+      const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(src_bits >> 32));
+      const char* usrc = reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
+      const unsigned lds = __builtin_amdgcn_readfirstlane(smem_addr + buf * S::BUF + (wave + 8 * e) * kWg32PieceStride);
+      const unsigned go = __builtin_amdgcn_readfirstlane((wave + 8 * e < S::PIECES) ? 1u : 0u);
+      const unsigned voff = lane16;
+      unsigned keep;
+      asm volatile(
+          "s_cmp_lg_u32 %[go], 0\n\t"
+          "s_cbranch_scc0 .Ldn_wg32_skip%=\n\t"
+          "s_mov_b32 %[keep], m0\n\t"
+          "s_mov_b32 m0, %[lds]\n\t"
+          "s_nop 1\n\t"
+          "global_load_lds_dwordx4 %[voff], %[sbase]" DN_WG_LOAD_POLICY "\n\t"
+          "s_mov_b32 m0, %[keep]\n"
+          ".Ldn_wg32_skip%=:"
+          : [keep] "=&s"(keep)
+          : [go] "s"(go), [lds] "s"(lds), [voff] "v"(voff), [sbase] "s"(usrc)
+          : "memory", "scc");
+    });
+  };
+  const bool full = (wave + 8 * (S::PER_WAVE - 1)) < S::PIECES;
+  auto wait_tile = [&]() {
+    if (full) wait_vmcnt<(S::STAGES - 2) * S::PER_WAVE>();
+    else wait_vmcnt<(S::STAGES - 2) * (S::PER_WAVE - 1)>();
+  };
+
+  f32x16 acc[S::J];
+#pragma unroll
+  for (int k = 0; k < S::J; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+
+  long long tile = wg;
+  int buf = 0;
+#pragma unroll 1
+  for (int st = 0; st + 1 < S::STAGES; ++st) stage(tile + static_cast<long long>(st) * n_wg, st);
+#pragma unroll 1
+  for (; tile < tiles; tile += n_wg) {
+    wait_tile();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+      int nb = buf + S::STAGES - 1;
+      if (nb >= S::STAGES) nb -= S::STAGES;
+      stage(tile + static_cast<long long>(S::STAGES - 1) * n_wg, nb);
+    }
+    const char* base = smem + buf * S::BUF;
+    // A: this wave's 32 output features (a custom dY is one piece: rows 4h+e of lanes i < 8, the rest zero)
+    const char* pa = S::CUSTOM ? base + ((i >> 2) & 1) * 32 * 16 + kk * 16 + (i & 3) * 4
+                               : base + ntile * 4 * kWg32PieceStride + feat_off;
+    const long long valid = p.n_points - tile * 32;
+    float a[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      a[m] = *reinterpret_cast<const float*>(pa + m * 32);
+      if (S::CUSTOM && i >= 8) a[m] = 0.0f;
+      if (2 * m + kk >= valid) a[m] = 0.0f;      // padding points of the last tile
+    }
+    static_for<S::J>([&](auto j_c) {
+      constexpr int j = decltype(j_c)::value;
+      const int kt = (S::KGROUPS == 1) ? j : kgroup + j * S::KGROUPS;   // kt >= KT: an unused accumulator
+      const int ktr = kt < S::KT - 1 ? kt : S::KT - 2;
+      // B: k-tile ktr.  Hidden tiles: 4 pieces each in feature order; PE tiles: a 64-wide panel is two tiles (lane half
+      // = tile), a 32-wide one a single tile (lane half = column / 16)
+      const char* pb;
+      if (ktr < S::XT) {
+        pb = base + (S::N_DY + 4 * ktr) * kWg32PieceStride + feat_off;
+      } else {
+        const int t = ktr - S::XT;
+        const int u = (S::PET == 2) ? i : (i & 15);
+        const int hh = (S::PET == 2) ? t : (i >> 4);
+        pb = base + (S::N_DY + S::N_X + (u >> 2)) * kWg32PieceStride + (hh * 32 + kk) * 16 + (u & 3) * 4;
+      }
+      const bool is_ones = kt >= S::KT - 1;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        float b = *reinterpret_cast<const float*>(pb + m * 32);
+        b = is_ones ? 1.0f : b;
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b, acc[j], 0, 0, 0);
+      }
+    });
+    buf = (buf + 1 == S::STAGES) ? 0 : buf + 1;
+  }
+  wait_vmcnt<0>();
+  // ---- epilogue: D[row][col] in lane (col = lane & 31, half = lane >> 5), register r, row = acc_row(r, half); operand rows
+  // and columns are in natural feature order here
+  const int col_l = lane & 31, half = lane >> 5;
+  static_for<S::J>([&](auto j_c) {
+    constexpr int j = decltype(j_c)::value;
+    const int kt = (S::KGROUPS == 1) ? j : kgroup + j * S::KGROUPS;
+    if (kt < S::KT) {
+      int col;
+      if (kt < S::XT) col = 32 * kt + col_l;
+      else if (kt < S::KT - 1) {
+        const int t = kt - S::XT;
+        const int u = (S::PET == 2) ? col_l : (col_l & 15);
+        const int hh = (S::PET == 2) ? t : (col_l >> 4);
+        const int pc = pe_slot_col(p.pe_L, hh, u);
+        col = pc >= 0 ? p.col_pe0 + pc : -1;
+      } else col = (col_l == 0) ? -2 : -1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int n = 32 * ntile + acc_row(r, half);
+        if constexpr (S::CUSTOM) {
+          n = acc_row(r, half);
+          if (n >= p.custom_rows) continue;
+        }
+        if (col >= 0) atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col, acc[j][r]);
+        else if (col == -2 && p.db != nullptr) atomicAdd(p.db + n, acc[j][r]);
+      }
+    }
+  });
+}
+
 // the instantiated layer shapes: W = 256 and W = 128 nets (L_xyz = 10: a 64-wide xyz panel = 2 tiles; L_dir: 1 tile)
 #define DN_WG_SHAPES(X)                                                                                        \
   X(0, 8, 0, 2, false) X(1, 8, 8, 0, false) X(2, 8, 8, 2, false) X(3, 4, 8, 1, false) X(4, 1, 8, 0, true)     \
@@ -779,6 +947,21 @@ __device__ __forceinline__ void weight_grad_dispatch(const WgParams& p, int wg, 
   }
 }
 
+__device__ __forceinline__ void weight_grad_dispatch_f32(const WgParams& p, int wg, int n_wg, char* smem) {
+  switch (p.shape) {
+#define X(id, a, b, c, d) case id: weight_grad_unit_f32<WgShape32<a, b, c, d>>(p, wg, n_wg, smem); break;
+    DN_WG_SHAPES(X)
+#undef X
+    default: break;
+  }
+}
+static int wg_shape_pieces_f32(int shape) {
+#define X(id, a, b, c, d) if (shape == id) return WgShape32<a, b, c, d>::PIECES;
+  DN_WG_SHAPES(X)
+#undef X
+  return 0;
+}
+
 __global__ __launch_bounds__(512, 2) void weight_grad_kernel(WgParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   weight_grad_dispatch(p, blockIdx.x, gridDim.x, smem);
@@ -802,6 +985,14 @@ __global__ __launch_bounds__(512, 2) void weight_grad_batch_kernel(WgBatch b) {
   weight_grad_dispatch(p, static_cast<int>(blockIdx.x) - b.wg_begin[u], b.wg_begin[u + 1] - b.wg_begin[u], smem);
 }
 
+__global__ __launch_bounds__(512, 2) void weight_grad_batch_kernel_f32(WgBatch b) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int u = 0;
+  while (u + 1 < b.n_units && static_cast<int>(blockIdx.x) >= b.wg_begin[u + 1]) ++u;
+  const WgParams p = b.u[u];
+  weight_grad_dispatch_f32(p, static_cast<int>(blockIdx.x) - b.wg_begin[u], b.wg_begin[u + 1] - b.wg_begin[u], smem);
+}
+
 static int wg_fill(const dn_mlp_desc* desc, const TrainLayout& t, const void* act, const void* grads, int64_t n_points,
                    int g_slot, int n_out, int x_slot, int x_width, int pe_kind, float* dW, int ldw, float* db, WgParams* out) {
   const int custom_rows = (n_out < 32) ? n_out : 0;  // fc_rgb (3) / fc_alpha (1) / fc_out (4): one custom dY piece
@@ -815,7 +1006,7 @@ static int wg_fill(const dn_mlp_desc* desc, const TrainLayout& t, const void* ac
   p.g_slot = g_slot; p.custom_rows = custom_rows;
   p.x_slot = x_slot;
   p.pe_slot = pe_kind == 1 ? t.slot_xyz : t.slot_dir;
-  const int pe_tiles = pe_kind == 0 ? 0 : (pe_kind == 1 ? t.kxp : t.kdp) / 2;
+  const int pe_tiles = pe_kind == 0 ? 0 : (pe_kind == 1 ? t.kxp : t.kdp) / t.ppt;   // pieces per 32-column tile: 2 (bf16) / 4 (fp32)
   p.pe_L = pe_kind == 1 ? desc->num_encoding_fn_xyz : desc->num_encoding_fn_dir;
   p.dW = dW; p.ldw = ldw; p.col_pe0 = x_width; p.db = db;
   p.shape = wg_shape_index(n_out / 32, x_width / 32, pe_tiles, custom_rows > 0);
@@ -846,7 +1037,8 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
                                       int64_t n_points, float* const* h_dW, float* const* h_db, dn_stream_t stream) {
   int rc = validate_desc(desc, precision);
   if (rc) return rc;
-  DN_REQUIRE(precision == DN_PREC_BF16, "dn_mlp_weight_grad_all: bf16 buffers only (fp32 mode forms dW with library GEMMs)");
+  DN_REQUIRE(precision == DN_PREC_BF16 || precision == DN_PREC_F32, "dn_mlp_weight_grad_all: bf16 or fp32 buffers (fp16 is a render-only mode)");
+  const bool f32 = precision == DN_PREC_F32;
   DN_REQUIRE(act && grads && h_dW && h_db && n_points >= 0, "dn_mlp_weight_grad_all: bad arguments");
   DN_REQUIRE(desc->num_encoding_fn_xyz == 10, "dn_mlp_weight_grad_all: training kernels are built for L_xyz = 10");
   if (n_points == 0) return 0;
@@ -892,7 +1084,7 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
   if (total_wg < n_units) total_wg = n_units;
   long long cost[kWgMaxUnits], cost_sum = 0;
   for (int i = 0; i < n_units; ++i) {
-    cost[i] = wg_shape_pieces(b.u[i].shape);
+    cost[i] = f32 ? wg_shape_pieces_f32(b.u[i].shape) : wg_shape_pieces(b.u[i].shape);
     cost_sum += cost[i];
   }
   int share[kWgMaxUnits], given = 0;
@@ -916,10 +1108,15 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
   static thread_local bool attr_set = false;
   if (!attr_set) {
     if ((rc = wg_attr(weight_grad_batch_kernel))) return rc;
+    if ((rc = wg_attr(weight_grad_batch_kernel_f32))) return rc;
     attr_set = true;
   }
-  hipLaunchKernelGGL(weight_grad_batch_kernel, dim3(static_cast<unsigned>(b.wg_begin[n_units])), dim3(512), kWgLdsBytes,
-                     as_stream(stream), b);
+  if (f32)
+    hipLaunchKernelGGL(weight_grad_batch_kernel_f32, dim3(static_cast<unsigned>(b.wg_begin[n_units])), dim3(512), 158 * 1024,
+                       as_stream(stream), b);
+  else
+    hipLaunchKernelGGL(weight_grad_batch_kernel, dim3(static_cast<unsigned>(b.wg_begin[n_units])), dim3(512), kWgLdsBytes,
+                       as_stream(stream), b);
   return check_launch("dn_mlp_weight_grad_all");
 }
 

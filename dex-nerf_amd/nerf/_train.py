@@ -3,8 +3,12 @@
 Inference: one fused kernel (positional encoding + MLP).  Training, for the nets the training kernels cover
 (W in {128, 256}, L_xyz = 10): `FusedNetFn` - a fused forward that keeps every stage's output and ReLU masks in a
 wave-native layout, and a fused backward-data chain on the transposed weight stream (dn_mlp_backward_data);
-the weight/bias gradients are then dY^T X GEMMs (library GEMM) over the unpacked rows.  Other configurations
+the weight/bias gradients come from one weight-gradient kernel launch per network on the saved native buffers
+(bf16 MFMA, or exact-fp32 MFMA in the parity mode; DEXNERF_FP32_DW=gemm selects the older fp32 route: unpack to plain rows
++ library GEMMs).  Other configurations
 differentiate the nn.Linear composition directly."""
+import os
+
 import torch
 
 from . import _hip, _ops
@@ -84,7 +88,7 @@ class FusedNetFn(torch.autograd.Function):
         def put(mod, dy, x):
             results[mod] = (dy.t() @ x, dy.sum(0))
 
-        if pk.precision == _hip.PREC_BF16:
+        if pk.precision == _hip.PREC_BF16 or os.environ.get("DEXNERF_FP32_DW", "kernel") != "gemm":
             # every layer's weight/bias gradient straight from the native buffers, one launch (MFMA kernel, fp32 atomics)
             mods = model.linear_modules()
             res = _ops.mlp_weight_grad_all(pk, act, grads, n, [tuple(m.weight.shape) for m in mods])

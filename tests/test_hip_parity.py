@@ -942,3 +942,54 @@ def test_data_parallel_training_loop_two_ranks_one_gpu(dev, tmp_path):
     for key in ("model_coarse_state_dict", "model_fine_state_dict"):
         for name in a[key]:
             assert torch.equal(a[key][name], b[key][name]), (key, name)    # replicas stayed bit-identical
+
+
+def test_fp32_weight_grad_kernel_against_unpacked_gemms(dev):
+    """Exact-fp32 weight-gradient kernel (v_mfma_f32_32x32x2_f32 on the native fp32 buffers, one launch per network)
+    against dY^T X formed with float64 matmuls on the unpacked rows, every layer incl. the skip layer's positional-encoding
+    columns, the view-direction layer and the 3-/1-row heads; ragged point count."""
+    import nerf
+    from nerf import _ops, _train, synthetic as syn
+    nerf.set_precision("fp32")
+    for kw in (dict(num_layers=8, hidden_size=256, skip_connect_every=4), dict(num_layers=5, hidden_size=128, skip_connect_every=2),
+               dict(num_layers=3, hidden_size=128, skip_connect_every=4, use_viewdirs=False)):
+        kw = dict(dict(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True), **kw)
+        m = nerf.models.FlexibleNeRFModel(**kw)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(11, sigma_gain=5.0, sigma_bias=0.0, **kw).items()})
+        m = m.to(dev)
+        n_rays, s = 45, 23     # 1035 points
+        pts = torch.randn(n_rays * s, 3, device=dev)
+        vd = torch.nn.functional.normalize(torch.randn(n_rays, 3, device=dev), dim=-1) if kw["use_viewdirs"] else None
+        pk = m.packed()
+        mods = m.linear_modules()
+        _ops.pack_backward(pk, [x.weight for x in mods])
+        out, act, masks = _ops.run_network_train(pk, pts, vd, s)
+        n = out.shape[0]
+        g = torch.randn(n, 4, device=dev)
+        grads = _ops.mlp_backward_data(pk, g, masks, n)
+        res = dict(zip(mods, _ops.mlp_weight_grad_all(pk, act, grads, n, [tuple(x.weight.shape) for x in mods])))
+        slots, gslots, kh = _train._slots(m, pk.precision)
+        w = m.hidden_size
+
+        def rows(which, buf, slot, width, kind=0):
+            return _ops.mlp_unpack(pk, which, buf, n, slot, width, kind, torch.empty((n, width), dtype=torch.float32, device=dev)).double()
+
+        pe_xyz = rows(0, act, slots["xyz"], m.dim_xyz, 1)
+        checks = [(m.layer1, rows(1, grads, gslots["layer1"], w), pe_xyz)]
+        x_prev = rows(0, act, slots["layer1"], w)
+        for i, layer in enumerate(m.layers_xyz):
+            x = torch.cat((x_prev, pe_xyz), -1) if i in m.skip_layers else x_prev
+            checks.append((layer, rows(1, grads, gslots["trunk0"] + i * kh, w), x))
+            x_prev = rows(0, act, slots["trunk0"] + i * kh, w)
+        if m.use_viewdirs:
+            checks.append((m.fc_feat, rows(1, grads, gslots["feat"], w), x_prev))
+            checks.append((m.fc_alpha, g[:, 3:4].double(), x_prev))
+            x_dir = torch.cat((rows(0, act, slots["feat"], w), rows(0, act, slots["dir"], m.dim_dir, 2)), -1)
+            checks.append((m.layers_dir[0], rows(1, grads, gslots["dirout"], w // 2), x_dir))
+            checks.append((m.fc_rgb, g[:, :3].double(), rows(0, act, slots["dirout"], w // 2)))
+        else:
+            checks.append((m.fc_out, g.double(), x_prev))
+        for mod, dy, x in checks:
+            d_w, d_b = res[mod]
+            assert rel_err(C(d_w), C(dy.t() @ x)) < 2e-5, (kw, mod)
+            assert rel_err(C(d_b), C(dy.sum(0))) < 2e-5, (kw, mod)

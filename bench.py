@@ -277,6 +277,13 @@ def main():
         if not args.no_train and world == 1:
             result["train"] = train_rate(models, cfg, ro, rd, ex, ed)
         if not args.no_train and world == 1 and args.precision == "bf16":
+            # the same iteration in the exact-fp32 parity mode (BASELINE config 5 trains in fp32): informational
+            nerf.set_precision("fp32")
+            try:
+                models32, cfg32, _, _, _, _ = build_scene(dev, rank)
+                result["train_fp32_mode"] = train_rate(models32, cfg32, ro, rd, ex, ed, steps=4)
+            finally:
+                nerf.set_precision(args.precision)
             # BASELINE config 3 as a shape: the as-shipped 4 x 128 nets, 1024 rays per step, 64+64 samples, whole iteration
             # replayed as one HIP graph by the build-owned driver (informational; a few seconds)
             try:

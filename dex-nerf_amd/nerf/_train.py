@@ -52,7 +52,7 @@ class FusedNetFn(torch.autograd.Function):
         pk = model.packed(log_xyz, log_dir)
         mods = model.linear_modules()
         key = model.param_key()
-        if pk.key_bwd != key:
+        if pk.key_bwd != key or torch.cuda.is_current_stream_capturing():
             _ops.pack_backward(pk, [m.weight for m in mods])
             pk.key_bwd = key
         if samples_per_ray is None:

@@ -98,7 +98,9 @@ class FlexibleNeRFModel(torch.nn.Module):
         if pk is None:
             pk = _ops.PackedMLP(self.desc_kwargs(log_sampling_xyz, log_sampling_dir), dev, prec)
             self._packed[slot] = pk
-        if pk.key != key:
+        # under stream capture always (re)pack: a captured graph must contain the pack of the weights it runs on, whatever
+        # the host-side cache believes at capture time
+        if pk.key != key or (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
             pk.pack([m.weight for m in mods], [m.bias for m in mods])
             pk.key = key
         return pk

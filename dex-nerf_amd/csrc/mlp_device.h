@@ -168,8 +168,13 @@ struct Pipe {
   }
 
   __device__ __forceinline__ void advance_issue() {
-    pend_src = q_issue + wave * (PER_WAVE * kPieceBytes);
-    pend_dst = slot_wr * kSlotBytes + wave * (PER_WAVE * kPieceBytes);
+#ifdef DN_EXP_ROTATE  // experiment: which wave fetches which pieces of a phase rotates with the workgroup's index in its XCD
+    const unsigned who = (wave + (blockIdx.x >> 3)) % WAVES;
+#else
+    const unsigned who = wave;
+#endif
+    pend_src = q_issue + who * (PER_WAVE * kPieceBytes);
+    pend_dst = slot_wr * kSlotBytes + who * (PER_WAVE * kPieceBytes);
     q_issue += kSlotBytes;
     if (q_issue >= total_bytes) q_issue = 0;
     slot_wr = (slot_wr + 1 == kRingPhases) ? 0 : slot_wr + 1;

@@ -5,7 +5,9 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 for tag in "$@"; do
-  if [ "$tag" = base ]; then unset DEXNERF_HIP_LIB; else export DEXNERF_HIP_LIB=exp_libs/lib$tag.so; fi
+  unset DEXNERF_HIP_LIB DEXNERF_BF16_PT
+  if [ "$tag" = pt2 ]; then export DEXNERF_BF16_PT=2   # shipped library, 4 waves x 64 points
+  elif [ "$tag" != base ]; then export DEXNERF_HIP_LIB=exp_libs/lib$tag.so; fi
   rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv \
       -d gpurun_out/abl_$tag -- python3 scripts/quick_time.py bf16 160000 > gpurun_out/abl_$tag.log 2>&1 || { echo "$tag: profiler run failed"; tail -3 gpurun_out/abl_$tag.log; exit 1; }
   echo "done $tag"

@@ -88,13 +88,27 @@ def time_dominant_kernel(models, ro, rd, precision, reps=5):
     return t, flops / t / 1e12
 
 
+def geometry48(precision):
+    """True when the bf16 fine-net launch runs the 48-points-per-wave kernel (the default; DEXNERF_BF16_GEOM=32 keeps the 32-point one)."""
+    return precision == "bf16" and os.environ.get("DEXNERF_BF16_GEOM", "") != "32"
+
+
 def pmc_traffic(precision):
     """HBM bytes per fine-net launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE, profiles/r01_pmc_fine_net.json); bench.py itself cannot run the profiler."""
+    WRITE_SIZE, profiles/r01_pmc_fine_net.json); bench.py itself cannot run the profiler.  That pass exists for the
+    32-point kernel only (it no longer completes on this pool): null for the 48-point kernel, whose estimate from the
+    L2-miss count is reported beside it as `traffic_estimate`."""
     path = os.path.join(REPO, "profiles", "r01_pmc_fine_net.json")
-    if precision != "bf16" or not os.path.exists(path):
+    if precision != "bf16" or not os.path.exists(path) or geometry48(precision):
         return None
     return json.load(open(path))["hbm_bytes_per_launch"]
+
+
+def pmc_traffic_estimate(precision):
+    path = os.path.join(REPO, "profiles", "r01_pmc_fine_net.json")
+    if not geometry48(precision) or not os.path.exists(path):
+        return None
+    return json.load(open(path)).get("g48_build", {}).get("hbm_bytes_per_launch_estimate")
 
 
 def library_gemm_tflops(dev, precision):
@@ -247,7 +261,8 @@ def main():
                                    "validation mode (det. resampling, no noise)",
                        "rays_per_step_per_gpu": H * W, "sharding": f"{world} ranks x own view (no collective in the path)"},
             "roofline": {"bound": "mfma", "achieved": ktf, "peak": peak, "unit": "TFLOP/s", "frac": ktf / peak,
-                         "traffic": pmc_traffic(args.precision), "kernel": "mlp_forward_kernel<256,10,4> (fine net, 160000x192 points)",
+                         "traffic": pmc_traffic(args.precision), "traffic_estimate": pmc_traffic_estimate(args.precision),
+                         "kernel": ("mlp_forward48_kernel<256>" if geometry48(args.precision) else "mlp_forward_kernel<256,10,4>") + " (fine net, 160000x192 points)",
                          "kernel_ms": kt * 1e3, "whole_path_tflops": whole_tf},
         }
         if world > 1:

@@ -19,6 +19,7 @@
 // chain also streams every stage's output pieces (non-temporal, scalar-base stores) and ReLU mask words to HBM.
 #include "mlp_device.h"
 #include "mlp_internal.h"
+#include "mlp_geo48.h"
 
 namespace dn {
 
@@ -491,6 +492,12 @@ int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStrea
 #define DN_CASE(W_, LX_)                                                                     \
   if (d.hidden_size == W_ && d.num_encoding_fn_xyz == LX_)                                   \
     return bf ? launch_forward<W_, LX_, 4, true, 1>(p, stream) : launch_forward<W_, LX_, 4, false, 1>(p, stream);
+  // bf16 inference from rays / points: the 48-points-per-wave geometry (mlp_fused48.hip) when the net fits it;
+  // DEXNERF_BF16_GEOM=32 keeps the 32-point kernels (same results up to bf16 accumulation order and the cosine's phase form)
+  const char* geom_env = getenv("DEXNERF_BF16_GEOM");   // read per call: tests and probes switch it within one process
+  const bool geom48 = !(geom_env && atoi(geom_env) == 32);
+  if (bf && geom48 && bf16_pt == 1 && p.mode != 2 && g48_supported(d, precision))
+    return launch_forward48(d, p, p.packed + p.bias_bytes + static_cast<size_t>(p.total_pieces) * kPieceBytes, stream);
   if (bf && bf16_pt == 2 && d.hidden_size == 256 && d.num_encoding_fn_xyz == 10)
     return launch_forward<256, 10, 4, true, 2>(p, stream);  // experimental 4-wave x 64-point geometry
   DN_CASE(256, 10)
@@ -539,7 +546,8 @@ extern "C" size_t dn_mlp_packed_bytes(const dn_mlp_desc* desc, int precision) {
   if (validate_desc(desc, precision)) return 0;
   NetLayout L;
   build_layout(*desc, precision, &L);
-  return static_cast<size_t>(L.bias_bytes) + static_cast<size_t>(L.total_pieces) * kPieceBytes;
+  return static_cast<size_t>(L.bias_bytes) + static_cast<size_t>(L.total_pieces) * kPieceBytes +
+         (g48_supported(*desc, precision) ? g48_region_bytes(*desc) : 0);
 }
 
 extern "C" int dn_mlp_pack(const dn_mlp_desc* desc, int precision, const float* const* h_weights,
@@ -557,7 +565,11 @@ extern "C" int dn_mlp_pack(const dn_mlp_desc* desc, int precision, const float* 
     ptrs.w[i] = h_weights[i];
     ptrs.b[i] = h_biases[i];
   }
-  return launch_pack(L, ptrs, packed, precision, as_stream(stream));
+  rc = launch_pack(L, ptrs, packed, precision, as_stream(stream));
+  if (rc == 0 && g48_supported(*desc, precision))
+    rc = launch_pack48(*desc, ptrs, static_cast<char*>(packed) + L.bias_bytes + static_cast<size_t>(L.total_pieces) * kPieceBytes,
+                       as_stream(stream));
+  return rc;
 }
 
 extern "C" int dn_run_network(const dn_mlp_desc* desc, int precision, const void* packed, const float* pts,

@@ -1,0 +1,430 @@
+// bf16 inference forward in the 48-points-per-wave geometry (see mlp_geo48.h): fused positional encoding +
+// FlexibleNeRFModel forward (reference run_network, nerf/train_utils.py:72-89; positional_encoding
+// nerf/nerf_helpers.py:115-159; FlexibleNeRFModel.forward nerf/models.py:233-256), same design as mlp_fused.hip -
+// persistent workgroups, register-resident activation chain, LDS-DMA weight ring (Pipe<8>) - on
+// v_mfma_f32_16x16x32_bf16: lane l of a wave holds point (l & 15) of each of its three 16-point groups and lane group
+// g = l >> 4 holds rows 4g..4g+3 of every 16-row accumulator tile, which is k-block g of the next layer's B operand.
+// Every A fragment read from LDS feeds three MFMAs: 384 points per pass of the weight stream instead of 256.
+// A-fragment FIFO of 2 pieces here (4 in the 32-point kernels): a piece lasts three MFMAs = 48 cycles, and the 256-VGPR
+// budget of two waves per SIMD is spent on the two 96-register activation sets
+#ifndef DN_G48_PREFETCH
+#define DN_G48_PREFETCH 2
+#endif
+#define DN_PREFETCH DN_G48_PREFETCH
+#include "mlp_geo48.h"
+
+namespace dn {
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// One GEMM stage: NT_OUT 16-row output tiles, KH hidden pieces + KP encoding pieces per tile, three point groups.
+template <int NT_OUT, int KH, int KP, int POS0, class PipeT, class BH, class BP, class Emit>
+__device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, const char* bias_g, Emit&& emit) {
+  constexpr int PT = 3, KT = KH + KP;
+  static_for<NT_OUT>([&](auto nt_c) {
+    constexpr int nt = decltype(nt_c)::value;
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias_g + nt * 64);
+    f32x4 acc[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) acc[t] = b;
+    static_for<KT>([&](auto k_c) {
+      constexpr int k = decltype(k_c)::value;
+      constexpr int pos = POS0 + nt * KT + k;
+      if constexpr (pos % kPhasePieces == 0) pipe.phase_begin();
+      if constexpr (pos % kPhasePieces == kPhasePieces / 2) pipe.mid_phase();
+      const bf16x8 a = __builtin_bit_cast(bf16x8, pipe.af[pos % kPrefetch]);
+      static_for<PT>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        if constexpr (k < KH) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh[t][k], acc[t], 0, 0, 0);
+        else acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bp(t, k - KH), acc[t], 0, 0, 0);
+      });
+      pipe.template prefetch<pos>();
+      __builtin_amdgcn_sched_group_barrier(0x008, PT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<PT>([&](auto t_c) { emit(nt_c, t_c, acc[decltype(t_c)::value]); });
+  });
+}
+
+// rows 4g..4g+3 of output tile NT -> elements (NT & 1) * 4 .. + 3 of B piece NT / 2 (g48_hidden_col)
+template <bool RELU, int NT, class BO>
+__device__ __forceinline__ void emit48(const f32x4& acc, BO& bo) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w = __builtin_bit_cast(u32x4, bo[NT / 2]);
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const f32x2 f = {acc[2 * d], acc[2 * d + 1]};
+    bf16x2 v = __builtin_convertvector(f, bf16x2);  // one v_cvt_pk_bf16_f32
+    if constexpr (RELU) {  // a negative bf16 is a negative int16 (mlp_device.h make_piece)
+      s16x2 bits = __builtin_bit_cast(s16x2, v);
+      const s16x2 zero = {0, 0};
+      bits = __builtin_elementwise_max(bits, zero);
+      v = __builtin_bit_cast(bf16x2, bits);
+    }
+    w[(NT & 1) * 2 + d] = __builtin_bit_cast(unsigned, v);
+  }
+  bo[NT / 2] = __builtin_bit_cast(bf16x8, w);
+}
+
+// one encoding slot: table entry = (frequency, comp | kind << 2), kind 0 identity, 1 sin, 2 cos, 3 padding.
+// Decoded with arithmetic on 0/1 floats, not selects: per-lane compares land in SGPR pairs, and ~40 of them per block
+// spilled scalar registers into VGPR lanes and, through that, finished activation pieces to scratch.
+// One hardware sine per slot: cos(2 pi r) = sin(2 pi (r + 1/4)) (revolutions, as mlp_device.h encode_pieces in bf16 mode).
+__device__ __forceinline__ float pe_value(const float (&x)[3], float2 entry) {
+  const unsigned code = __float_as_uint(entry.y);
+  const float m1 = static_cast<float>(code & 1u), m2 = static_cast<float>((code >> 1) & 1u), m0 = 1.0f - m1 - m2;
+  const float k0 = static_cast<float>((code >> 2) & 1u), k1 = static_cast<float>((code >> 3) & 1u);
+  const float xc = m0 * x[0] + m1 * x[1] + m2 * x[2];   // one-hot: exact
+  const float arg = xc * entry.x;
+  const float rev = __builtin_amdgcn_fractf(arg * 0.15915494309189535f) + 0.25f * (k1 * (1.0f - k0));
+  const float s = __builtin_amdgcn_sinf(rev);
+  const float trig = k0 + k1 - 2.0f * k0 * k1, ident = (1.0f - k0) * (1.0f - k1);
+  return ident * xc + trig * s;
+}
+
+template <int W>
+__global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdParams p, G48Params q) {
+  constexpr int PT = 3;
+  constexpr int NT = W / 16;
+  constexpr int KH = W / 32;
+  constexpr int KXP = kG48XyzPieces, KDP = kG48DirPieces;
+  constexpr int WAVES = kG48Waves;
+  constexpr int PPW = kG48PointsPerWave;
+  constexpr int PPG = kG48PointsPerWg;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;
+  char* bias_lds = smem + kRingBytes;
+  const char* tab_lds = bias_lds + q.bias_bytes;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Lane-derived LDS addresses are NOT carried across the trunk (every carried VGPR is a spill at this register budget, and
+  // a spill reload waits with vmcnt(0), draining the weight pipeline): each use site rebuilds them from an opaque copy
+  // of the thread index, which the optimiser cannot merge with the other sites.
+  auto fresh_lane = [&]() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t & 63; };
+  auto pex_of = [&](int ln) { return smem + kRingBytes + q.bias_bytes + kG48TableBytes + wave * (PT * KXP * kPieceBytes) + ln * 16; };
+  // per-wave input rows of 48 floats: 0-2 origin / point, 3-5 direction, 6 depth, then two sets of 3 view-direction rows
+  // (the next tile is staged at the top of this one, when registers are free; the view direction of THIS tile is only
+  // consumed near its end, so those rows alternate between two sets)
+  float* inbuf = reinterpret_cast<float*>(smem + kRingBytes + q.bias_bytes + kG48TableBytes + WAVES * PT * KXP * kPieceBytes) +
+                 wave * (kG48InRows * PPW);   // wave-uniform
+
+  // inputs of a tile by 4-byte LDS-DMA: lane l < 48 stages point l of this wave (mlp_fused.hip issue_inputs)
+  auto issue_inputs = [&](long long tile, int vset) {
+    const int lane = fresh_lane();
+    long long pt = tile * PPG + wave * PPW + lane;
+    if (pt >= p.n_points) pt = p.n_points - 1;
+    auto dma = [&](const float* src, int row) {
+      if (lane < PPW)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(inbuf + row * PPW), 4, 0, 0);
+    };
+    if (p.mode == 0) {
+      const float* r = p.rays + (pt / p.S) * p.ray_stride;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dma(r + c, c);
+      dma(p.z + pt, 6);
+      if (p.use_viewdirs) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dma(r + 8 + c, 7 + 3 * vset + c);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dma(p.pts + pt * 3 + c, c);
+      if (p.use_viewdirs) {
+        const float* v = p.viewdirs + (pt / p.S) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dma(v + c, 7 + 3 * vset + c);
+      }
+    }
+  };
+
+  {  // bias rows + encoding tables -> LDS once per workgroup
+    const f32x4* gsrc = reinterpret_cast<const f32x4*>(q.base);
+    f32x4* l = reinterpret_cast<f32x4*>(bias_lds);
+    for (int i = threadIdx.x; i < (q.bias_bytes + kG48TableBytes) / 16; i += WAVES * 64) l[i] = gsrc[i];
+  }
+  issue_inputs(blockIdx.x, 0);
+
+  Pipe<WAVES> pipe;
+  pipe.ring = ring;
+  pipe.ring_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)ring));
+  pipe.lane16 = lane * 16;
+  pipe.wsrc = q.base + q.bias_bytes + kG48TableBytes;
+  pipe.total_bytes = static_cast<unsigned>(q.total_pieces) * kPieceBytes;
+  pipe.q_issue = 0;
+  pipe.slot_wr = 0;
+  pipe.wave = wave;
+#pragma unroll
+  for (int ph = 0; ph < kRingPhases - 1; ++ph) pipe.issue_phase();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  pipe.slot_nxt = 0;
+  pipe.rd_cur = ring + lane * 16;
+  pipe.rd_nxt = ring + lane * 16;
+#pragma unroll
+  for (int e = 0; e < kPrefetch; ++e) pipe.af[e] = *reinterpret_cast<const f32x4*>(pipe.rd_nxt + e * kPieceBytes);
+
+  const char* bias_g = bias_lds + (lane >> 4) * 16;  // this lane group's 4 rows of bias tile 0
+
+  int vset = 0;  // which view-direction rows hold this tile's directions (wave-uniform, flips every tile)
+  for (long long tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x, vset ^= 1) {
+    // ---- xyz encoding of this lane's three points, its 16 columns each, into the per-wave LDS stash ----
+    {
+      const int ln = fresh_lane();
+      const int j = ln & 15;
+      const float2* tabx = reinterpret_cast<const float2*>(tab_lds) + (ln >> 4) * 16;
+      char* pex = pex_of(ln);
+      float in[PT][7];
+#pragma unroll
+      for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int c = 0; c < 7; ++c) in[t][c] = inbuf[c * PPW + t * 16 + j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      {
+        const long long nxt = tile + gridDim.x;
+        if (nxt < p.n_tiles) issue_inputs(nxt, vset ^ 1);
+      }
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        float x[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)  // plain mul then add (train_utils.py:136)
+          x[c] = (p.mode == 0) ? in[t][c] + in[t][3 + c] * in[t][6] : in[t][c];
+#pragma unroll
+        for (int k = 0; k < KXP; ++k) {
+          bf16x8 piece;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) piece[e] = static_cast<__bf16>(pe_value(x, tabx[k * 8 + e]));
+          *reinterpret_cast<bf16x8*>(pex + (t * KXP + k) * kPieceBytes) = piece;
+        }
+      }
+    }
+    auto pe_xyz = [&](int t, int k) { return *reinterpret_cast<const bf16x8*>(pex_of(pipe.lane16 >> 4) + (t * KXP + k) * kPieceBytes); };
+    auto no_pe = [&](int, int) { return bf16x8{}; };
+
+    bf16x8 ba[PT][KH], bb[PT][KH];
+    bf16x8 none[PT][1];
+    int bias_tile = 0;
+    // ---- layer1: xyz encoding -> W, no activation (models.py:238) ----
+    run_stage48<NT, 0, KXP, 0>(pipe, none, pe_xyz, bias_g, [&](auto nt_c, auto t_c, const f32x4& acc) {
+      emit48<false, decltype(nt_c)::value>(acc, ba[decltype(t_c)::value]);
+    });
+    bias_tile += NT;
+    // ---- trunk (models.py:239-246), two layers per iteration: the activations ping-pong between two register sets ----
+    auto trunk_layer = [&](int i, const bf16x8 (&bin)[PT][KH], bf16x8 (&bout)[PT][KH]) __attribute__((always_inline)) {
+      auto emit = [&](auto nt_c, auto t_c, const f32x4& acc) {
+        emit48<true, decltype(nt_c)::value>(acc, bout[decltype(t_c)::value]);
+      };
+      if ((p.skip_mask >> i) & 1u) run_stage48<NT, KH, KXP, 0>(pipe, bin, pe_xyz, bias_g + bias_tile * 64, emit);
+      else run_stage48<NT, KH, 0, 0>(pipe, bin, no_pe, bias_g + bias_tile * 64, emit);
+      bias_tile += NT;
+    };
+    int i = 0;
+    for (; i + 1 < p.D - 1; i += 2) {
+      trunk_layer(i, ba, bb);
+      trunk_layer(i + 1, bb, ba);
+    }
+    if (i < p.D - 1) {
+      trunk_layer(i, ba, bb);
+#pragma unroll
+      for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int k = 0; k < KH; ++k) ba[t][k] = bb[t][k];
+    }
+    float out4[PT][4];
+    if (p.use_viewdirs) {
+      // ---- fc_alpha (its own 16-row tile, row 0, streamed first) + fc_feat with ReLU (models.py:248-249) ----
+      run_stage48<1, KH, 0, 0>(pipe, ba, no_pe, bias_g + bias_tile * 64, [&](auto, auto t_c, const f32x4& acc) {
+        out4[decltype(t_c)::value][3] = acc[0];  // row 0 lives in lane group 0, register 0
+      });
+      run_stage48<NT, KH, 0, KH % kPhasePieces>(pipe, ba, no_pe, bias_g + (bias_tile + 1) * 64, [&](auto nt_c, auto t_c, const f32x4& acc) {
+        emit48<true, decltype(nt_c)::value>(acc, bb[decltype(t_c)::value]);
+      });
+      bias_tile += NT + 1;
+      // ---- view-direction encoding (one 32-deep piece per point group) ----
+      // fenced on both sides: interleaved into the fc_feat MFMAs its temporaries push finished activation pieces to scratch
+      __builtin_amdgcn_sched_barrier(0);
+      // (one point group at a time, into the xyz stash - dead once the trunk is done - so that neither the block's
+      // temporaries nor the pieces themselves compete with the 96 registers of fc_feat's output)
+      {
+        const int ln = fresh_lane();
+        const int j = ln & 15;
+        const float2* tabd = reinterpret_cast<const float2*>(tab_lds + 512) + (ln >> 4) * 8;
+        char* pex = pex_of(ln);
+        static_for<PT>([&](auto t_c) {
+          constexpr int t = decltype(t_c)::value;
+          float v[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) v[c] = inbuf[(7 + 3 * vset + c) * PPW + t * 16 + j];
+          bf16x8 piece;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) piece[e] = static_cast<__bf16>(pe_value(v, tabd[e]));
+          *reinterpret_cast<bf16x8*>(pex + t * kPieceBytes) = piece;
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- layers_dir[0] on cat(feat, view) -> W/2, ReLU (models.py:250-252) ----
+      constexpr int POS_D = ((NT + 1) * KH) % kPhasePieces;
+      bf16x8 bg[PT][KH / 2];
+      auto pe_dir = [&](int t, int) { return *reinterpret_cast<const bf16x8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes); };
+      run_stage48<NT / 2, KH, KDP, POS_D>(pipe, bb, pe_dir, bias_g + bias_tile * 64, [&](auto nt_c, auto t_c, const f32x4& acc) {
+        emit48<true, decltype(nt_c)::value>(acc, bg[decltype(t_c)::value]);
+      });
+      bias_tile += NT / 2;
+      // ---- fc_rgb (models.py:253) ----
+      constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % kPhasePieces;
+      run_stage48<1, KH / 2, 0, POS_R>(pipe, bg, no_pe, bias_g + bias_tile * 64, [&](auto, auto t_c, const f32x4& acc) {
+        constexpr int t = decltype(t_c)::value;
+        out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2];
+      });
+      constexpr int END = POS_R + KH / 2;
+      static_assert(END <= kPhasePieces, "the tail stays inside one phase");
+      if constexpr (END % kPhasePieces != 0) pipe.template skip<END, kPhasePieces - END>();
+    } else {
+      // ---- fc_out (models.py:256) ----
+      run_stage48<1, KH, 0, 0>(pipe, ba, no_pe, bias_g + bias_tile * 64, [&](auto, auto t_c, const f32x4& acc) {
+        constexpr int t = decltype(t_c)::value;
+        out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2]; out4[t][3] = acc[3];
+      });
+      if constexpr (KH % kPhasePieces != 0) pipe.template skip<KH % kPhasePieces, kPhasePieces - KH % kPhasePieces>();
+    }
+    const int lo = fresh_lane();
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const long long pt = tile * PPG + wave * PPW + t * 16 + (lo & 15);
+      if (pt < p.n_points && lo < 16) {
+        f32x4 o;
+        o[0] = out4[t][0]; o[1] = out4[t][1]; o[2] = out4[t][2]; o[3] = out4[t][3];
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p.out + pt * 4));
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+// ---- pack: nn.Linear tensors -> bias rows + encoding tables + 16x32 A pieces -----------------------------------
+__global__ void pack48_kernel(NetLayout L, PackPtrs ptrs, G48Tables tabs, char* __restrict__ region) {
+  const int DX = 3 + 6 * L.LX, DD = 3 + 6 * L.LD;
+  const int n_rows = L.total_bias_tiles * 16;
+  float* bias_out = reinterpret_cast<float*>(region);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < L.bias_bytes / 4; idx += gridDim.x * blockDim.x) {
+    float v = 0.0f;
+    if (idx < n_rows) {
+      const int tile = idx / 16, r = idx % 16;
+      int s = 0;
+      while (s + 1 < L.n_stages && L.st[s + 1].bias0 <= tile) ++s;
+      const StageDesc& st = L.st[s];
+      const int ts = tile - st.bias0;
+      if (st.src2 >= 0) {
+        if (ts == 0) v = (r == 0) ? ptrs.b[st.src2][0] : 0.0f;
+        else { const int n = (ts - 1) * 16 + r; v = (n < st.n_real) ? ptrs.b[st.src][n] : 0.0f; }
+      } else {
+        const int n = ts * 16 + r;
+        v = (n < st.n_real) ? ptrs.b[st.src][n] : 0.0f;
+      }
+    }
+    bias_out[idx] = v;
+  }
+  // encoding tables: [4][16] xyz entries, then (at byte 512) [4][8] dir entries
+  float2* tab = reinterpret_cast<float2*>(region + L.bias_bytes);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < kG48TableBytes / 8; idx += gridDim.x * blockDim.x) {
+    int kind_pe, gg, u, width;
+    if (idx < 64) { kind_pe = 1; gg = idx / 16; u = idx % 16; width = DX; }
+    else if (idx < 96) { kind_pe = 2; gg = (idx - 64) / 8; u = (idx - 64) % 8; width = DD; }
+    else { kind_pe = 0; gg = 0; u = 0; width = 0; }
+    float freq = 0.0f;
+    int comp = 0, kind = 3;
+    if (kind_pe) {
+      const int c = g48_pe_col(kind_pe, gg, u);
+      if (c < 3) { kind = 0; comp = c; }
+      else if (c < width) {
+        const int qq = c - 3, f = qq / 6, r = qq % 6;
+        kind = r < 3 ? 1 : 2; comp = r % 3;
+        freq = kind_pe == 1 ? tabs.fx[f] : tabs.fd[f];
+      }
+    }
+    tab[idx] = make_float2(freq, __int_as_float(comp | (kind << 2)));
+  }
+  // pieces
+  __bf16* wout = reinterpret_cast<__bf16*>(region + L.bias_bytes + kG48TableBytes);
+  const long long n_elems = static_cast<long long>(L.total_pieces) * 64 * 8;
+  for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < n_elems;
+       idx += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int e = static_cast<int>(idx % 8);
+    const int lane = static_cast<int>((idx / 8) % 64);
+    const int piece = static_cast<int>(idx / 512);
+    const int i = lane & 15, gg = lane >> 4;
+    float v = 0.0f;
+    int s = 0;
+    while (s + 1 < L.n_stages && L.st[s + 1].piece0 <= piece) ++s;
+    const StageDesc& st = L.st[s];
+    const int rel = piece - st.piece0;
+    if (rel < st.n_tiles * st.pieces_per_tile) {
+      const int ts = rel / st.pieces_per_tile;
+      const int k = rel % st.pieces_per_tile;
+      const int kh = st.hidden_in / 32;
+      int col;
+      if (k < kh) {
+        col = st.col_hidden0 + g48_hidden_col(k, gg, e);
+      } else {
+        const int pc = g48_pe_col(st.pe_kind, gg, (k - kh) * 8 + e);
+        col = (pc < (st.pe_kind == 1 ? DX : DD)) ? st.col_pe0 + pc : -1;
+      }
+      if (col >= 0) {
+        if (st.src2 >= 0) {
+          if (ts == 0) v = (i == 0) ? ptrs.w[st.src2][col] : 0.0f;
+          else { const int n = (ts - 1) * 16 + i; v = (n < st.n_real) ? ptrs.w[st.src][static_cast<long long>(n) * st.ld + col] : 0.0f; }
+        } else {
+          const int n = ts * 16 + i;
+          v = (n < st.n_real) ? ptrs.w[st.src][static_cast<long long>(n) * st.ld + col] : 0.0f;
+        }
+      }
+    }
+    wout[idx] = static_cast<__bf16>(v);
+  }
+}
+
+void fill_freqs(float* f, int num_fns, int log_sampling);  // rays_sampling.hip
+
+int launch_pack48(const dn_mlp_desc& d, const PackPtrs& ptrs, char* region, hipStream_t stream) {
+  NetLayout L;
+  build_layout48(d, &L);
+  G48Tables tabs{};
+  fill_freqs(tabs.fx, d.num_encoding_fn_xyz, d.log_sampling_xyz);
+  if (d.use_viewdirs) fill_freqs(tabs.fd, d.num_encoding_fn_dir, d.log_sampling_dir);
+  tabs.LX = d.num_encoding_fn_xyz; tabs.LD = d.num_encoding_fn_dir;
+  hipLaunchKernelGGL(pack48_kernel, dim3(512), dim3(256), 0, stream, L, ptrs, tabs, region);
+  return check_launch("mlp_pack48");
+}
+
+int launch_forward48(const dn_mlp_desc& d, const FwdParams& p_in, const char* region, hipStream_t stream) {
+  NetLayout L;
+  build_layout48(d, &L);
+  FwdParams p = p_in;
+  G48Params q{region, L.bias_bytes, L.total_pieces};
+  p.n_tiles = (p.n_points + kG48PointsPerWg - 1) / kG48PointsPerWg;
+  const size_t lds = g48_lds_bytes(L);
+  if (lds > 160 * 1024) { set_error("mlp_forward48: %zu bytes of LDS", lds); return DN_E_UNSUPPORTED; }
+  auto kern = mlp_forward48_kernel<256>;
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -static_cast<int>(e); }
+    attr_set = true;
+  }
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  const long long grid = p.n_tiles < cus ? p.n_tiles : cus;
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(kG48Waves * 64), lds, stream, p, q);
+  return check_launch("mlp_forward48");
+}
+
+}  // namespace dn

@@ -9,4 +9,6 @@ args = ["--iters", "150", "--size", "32", "--views", "6", "--num-random-rays", "
 args += ["--save", os.path.join(os.environ.get("CKDIR", "/tmp"), f"dp_rank{os.environ.get('RANK', '0')}.ckpt")]
 os.environ["DEXNERF_SAVE_ALL_RANKS"] = "1"
 res = train_dexnerf.main(args)
-print("RESULT", os.environ.get("RANK", "0"), res["history"][0][2], res["history"][-1][2], flush=True)
+# one write() per rank: print() with several arguments issues several writes, and two ranks share the pipe
+sys.stdout.write("RESULT %s %r %r\n" % (os.environ.get("RANK", "0"), res["history"][0][2], res["history"][-1][2]))
+sys.stdout.flush()

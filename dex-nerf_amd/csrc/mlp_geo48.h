@@ -14,12 +14,24 @@ constexpr int kG48PointsPerWave = 48;
 constexpr int kG48PointsPerWg = kG48Waves * kG48PointsPerWave;  // 384
 constexpr int kG48XyzPieces = kXyzPanel / 32;                   // 2
 constexpr int kG48DirPieces = 1;                                // 27 columns in one 32-deep piece
-constexpr int kG48TableBytes = 1024;                            // [4 groups][16 slots] xyz + [4][8] dir, 8 B each
+constexpr int kG48TableBytes = 1536;                            // [4 groups][16 slots] xyz + [4][8] dir entries of 16 B
 constexpr int kG48InRows = 13;                                  // per-wave input rows: 7 + two sets of 3 view-direction rows
 
-// Encoding column held in slot u of lane group g (= lane / 16): a group's slots of all PE pieces are consecutive columns
-// of the reference encoding [x(3), sin(f0 x)(3), cos(f0 x)(3), ...] (nerf/nerf_helpers.py:132-159); >= width: padding.
-__host__ __device__ constexpr int g48_pe_col(int kind, int g, int u) { return kind == 1 ? g * 16 + u : g * 8 + u; }
+// Encoding column held in slot u of lane group g (= lane / 16), or -1 for padding.  The coordinate a slot encodes is
+// (u + g) % 3, so that a lane rotates its point once ((x, y, z) -> starting at g % 3) and every slot then reads a
+// compile-time element of the rotated point; which function of that coordinate (identity / sin f / cos f) is table
+// data.  Per coordinate the slots, taken in (g, u) order, receive its columns of the reference encoding
+// [x(3), sin(f0 x)(3), cos(f0 x)(3), ...] (nerf/nerf_helpers.py:132-159) in order: identity, sin f0, cos f0, sin f1, ...
+__host__ __device__ inline int g48_pe_col(int kind, int g, int u, int L) {
+  const int slots = kind == 1 ? 16 : 8;
+  const int comp = (u + g) % 3;
+  int rank = 0;
+  for (int gg = 0; gg <= g; ++gg)
+    for (int uu = 0; uu < (gg == g ? u : slots); ++uu) rank += ((uu + gg) % 3 == comp) ? 1 : 0;
+  if (rank == 0) return comp;                       // identity column
+  const int f = (rank - 1) / 2, is_cos = (rank - 1) % 2;
+  return f < L ? 3 + 6 * f + 3 * is_cos + comp : -1;
+}
 
 // Hidden feature held by element e of lane group g in B piece k of a hidden vector: two 16-row output tiles (2k, 2k+1)
 // make one 32-deep piece; the 16x16 accumulator keeps rows 4g..4g+3 of a tile in lane group g.

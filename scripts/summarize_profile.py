@@ -41,7 +41,7 @@ lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
 for k, v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
     m = meta[k]
     lines.append(f"| {k} | {len(v)} | {sum(v) / len(v):.0f} | {min(v)} | {max(v)} | " + " | ".join(m) + " |")
-    if "mlp_forward_kernel" in k and len(v) > 2:
+    if ("mlp_forward_kernel" in k or "mlp_forward48_kernel" in k) and len(v) > 2:
         cut = (min(v) + max(v)) / 2
         small = [d for d in v if d < cut]
         big = [d for d in v if d >= cut]

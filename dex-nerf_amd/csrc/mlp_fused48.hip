@@ -422,18 +422,21 @@ int launch_forward48(const dn_mlp_desc& d, const FwdParams& p_in, const char* re
   p.n_tiles = (p.n_points + kG48PointsPerWg - 1) / kG48PointsPerWg;
   const size_t lds = g48_lds_bytes(L);
   if (lds > 160 * 1024) { set_error("mlp_forward48: %zu bytes of LDS", lds); return DN_E_UNSUPPORTED; }
-  auto kern = mlp_forward48_kernel<256>;
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -static_cast<int>(e); }
-    attr_set = true;
-  }
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
   const long long grid = p.n_tiles < cus ? p.n_tiles : cus;
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(kG48Waves * 64), lds, stream, p, q);
-  return check_launch("mlp_forward48");
+  auto launch = [&](auto kern, bool& attr_set) -> int {
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -static_cast<int>(e); }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(kG48Waves * 64), lds, stream, p, q);
+    return check_launch("mlp_forward48");
+  };
+  static thread_local bool attr256 = false, attr128 = false;
+  if (d.hidden_size == 256) return launch(mlp_forward48_kernel<256>, attr256);
+  return launch(mlp_forward48_kernel<128>, attr128);
 }
 
 }  // namespace dn

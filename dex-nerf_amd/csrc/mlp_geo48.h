@@ -97,9 +97,9 @@ inline size_t g48_lds_bytes(const NetLayout& L) {
          kG48Waves * kG48InRows * kG48PointsPerWave * sizeof(float);
 }
 
-// W = 256 bf16 nets whose bias rows leave room for the stash in 160 KiB of LDS (D <= 9 with view directions)
+// bf16 nets whose bias rows leave room for the stash in 160 KiB of LDS (W = 256: D <= 9 with view directions)
 inline bool g48_supported(const dn_mlp_desc& d, int precision) {
-  if (precision != DN_PREC_BF16 || d.hidden_size != 256) return false;
+  if (precision != DN_PREC_BF16 || (d.hidden_size != 256 && d.hidden_size != 128)) return false;
   NetLayout L;
   build_layout48(d, &L);
   return g48_lds_bytes(L) <= 160 * 1024;

@@ -1,4 +1,4 @@
-"""Developer stress run: random W=256 nets / point counts / input forms through the 48-points-per-wave bf16 inference kernel,
+"""Developer stress run: random W=128 / 256 nets / point counts / input forms through the 48-points-per-wave bf16 inference kernel,
 against the 32-point bf16 kernel (mean difference: layout check) and the exact-fp32 kernel (bf16-level error, equal for both)."""
 import os, sys
 import numpy as np, torch
@@ -12,8 +12,8 @@ n_cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 bad = 0
 for it in range(n_cfg):
     D = int(rng.integers(2, 10)); view = bool(rng.integers(0, 2)); skip = int(rng.choice([2, 3, 4, 5, 100]))
-    lx = int(rng.choice([10, 6])); logs = bool(rng.integers(0, 2))
-    kw = dict(num_layers=D, hidden_size=256, skip_connect_every=skip, num_encoding_fn_xyz=lx, num_encoding_fn_dir=4, use_viewdirs=view)
+    lx = int(rng.choice([10, 6])); logs = bool(rng.integers(0, 2)); width = int(rng.choice([128, 256]))
+    kw = dict(num_layers=D, hidden_size=width, skip_connect_every=skip, num_encoding_fn_xyz=lx, num_encoding_fn_dir=4, use_viewdirs=view)
     sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(int(rng.integers(1, 1000)), sigma_gain=5.0, sigma_bias=0.0, **kw).items()}
     packed = {}
     for prec in ("fp32", "bf16"):
@@ -42,7 +42,7 @@ for it in range(n_cfg):
         if not torch.isfinite(o48).all(): msgs.append(f"{form}: non-finite")
         if float(d.max()) > 8e-2 or (big and float(d.mean()) > 1e-4): msgs.append(f"{form}: 48 vs 32 mean {float(d.mean()):.2e} max {float(d.max()):.2e}")
         if big and abs(float(e48.mean()) - float(e32.mean())) > 0.15 * float(e32.mean()) + 1e-5: msgs.append(f"{form}: vs fp32 mean 48 {float(e48.mean()):.2e} / 32 {float(e32.mean()):.2e}")
-    tag = f"D{D} skip{skip} view{int(view)} LX{lx} log{int(logs)} rays{n_rays}x{s}"
+    tag = f"W{width} D{D} skip{skip} view{int(view)} LX{lx} log{int(logs)} rays{n_rays}x{s}"
     print(("BAD  " if msgs else "ok   ") + tag + ("  " + "; ".join(msgs) if msgs else ""), flush=True)
     bad += bool(msgs)
 nerf.set_precision("fp32")

@@ -1007,8 +1007,9 @@ def test_bf16_48_point_geometry_against_32_point_and_fp32(dev, monkeypatch):
     import nerf
     from nerf import _ops, synthetic as syn
     gen = torch.Generator(device="cpu").manual_seed(5)
-    for (D, view, skip) in [(8, True, 4), (8, False, 4), (5, True, 2), (2, True, 4), (3, False, 100), (9, True, 3)]:
-        kw = dict(num_layers=D, hidden_size=256, skip_connect_every=skip, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=view)
+    for (D, view, skip, width) in [(8, True, 4, 256), (8, False, 4, 256), (5, True, 2, 256), (2, True, 4, 256), (3, False, 100, 256),
+                                   (9, True, 3, 256), (4, True, 4, 128), (6, False, 2, 128), (3, True, 2, 128)]:
+        kw = dict(num_layers=D, hidden_size=width, skip_connect_every=skip, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=view)
         sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(11 + D, sigma_gain=5.0, sigma_bias=0.0, **kw).items()}
         packed = {}
         for prec in ("fp32", "bf16"):
@@ -1034,7 +1035,7 @@ def test_bf16_48_point_geometry_against_32_point_and_fp32(dev, monkeypatch):
                 monkeypatch.delenv("DEXNERF_BF16_GEOM")
                 o48 = run("bf16")
                 scale = float(ref.abs().max()) + 1e-6
-                case = (D, view, skip, n_rays, s, form)
+                case = (width, D, view, skip, n_rays, s, form)
                 assert torch.isfinite(o48).all(), case
                 d = (o48 - o32).abs() / scale
                 assert float(d.max()) < 8e-2, (case, float(d.max()))

@@ -474,6 +474,12 @@ int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStrea
   // bf16 geometry: PT=1 (8 waves x 32 points, two waves per SIMD) measured fastest (1327 vs 1277 TFLOP/s for
   // PT=2 = 4 waves x 64 points, one wave per SIMD); DEXNERF_BF16_PT=2 selects the latter for experiments
   static const int bf16_pt = [] { const char* e = getenv("DEXNERF_BF16_PT"); return (e && atoi(e) == 2) ? 2 : 1; }();
+  // bf16 / fp16 inference from rays / points: the 48-points-per-wave geometry (mlp_fused48.hip) when the net fits it;
+  // DEXNERF_BF16_GEOM=32 keeps the 32-point kernels (same results up to bf16 accumulation order and the cosine's phase form)
+  const char* geom_env = getenv("DEXNERF_BF16_GEOM");   // read per call: tests and probes switch it within one process
+  const bool geom48 = !(geom_env && atoi(geom_env) == 32);
+  if ((bf || hf) && geom48 && bf16_pt == 1 && p.act == nullptr && p.mode != 2 && p.n_points < (1LL << 31) - 1024 && g48_supported(d, precision))
+    return launch_forward48(d, precision, p, p.packed + p.bias_bytes + static_cast<size_t>(p.total_pieces) * kPieceBytes, stream);
   if (p.act != nullptr && hf) { set_error("mlp_forward(train): fp16 is a render-only mode"); return DN_E_UNSUPPORTED; }
   if (p.act != nullptr) {  // training forward: LX=10 nets, PT=1
     if (d.num_encoding_fn_xyz == 10 && d.hidden_size == 256)
@@ -492,12 +498,6 @@ int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStrea
 #define DN_CASE(W_, LX_)                                                                     \
   if (d.hidden_size == W_ && d.num_encoding_fn_xyz == LX_)                                   \
     return bf ? launch_forward<W_, LX_, 4, true, 1>(p, stream) : launch_forward<W_, LX_, 4, false, 1>(p, stream);
-  // bf16 inference from rays / points: the 48-points-per-wave geometry (mlp_fused48.hip) when the net fits it;
-  // DEXNERF_BF16_GEOM=32 keeps the 32-point kernels (same results up to bf16 accumulation order and the cosine's phase form)
-  const char* geom_env = getenv("DEXNERF_BF16_GEOM");   // read per call: tests and probes switch it within one process
-  const bool geom48 = !(geom_env && atoi(geom_env) == 32);
-  if (bf && geom48 && bf16_pt == 1 && p.mode != 2 && p.n_points < (1LL << 31) - 1024 && g48_supported(d, precision))
-    return launch_forward48(d, p, p.packed + p.bias_bytes + static_cast<size_t>(p.total_pieces) * kPieceBytes, stream);
   if (bf && bf16_pt == 2 && d.hidden_size == 256 && d.num_encoding_fn_xyz == 10)
     return launch_forward<256, 10, 4, true, 2>(p, stream);  // experimental 4-wave x 64-point geometry
   DN_CASE(256, 10)
@@ -567,7 +567,7 @@ extern "C" int dn_mlp_pack(const dn_mlp_desc* desc, int precision, const float* 
   }
   rc = launch_pack(L, ptrs, packed, precision, as_stream(stream));
   if (rc == 0 && g48_supported(*desc, precision))
-    rc = launch_pack48(*desc, ptrs, static_cast<char*>(packed) + L.bias_bytes + static_cast<size_t>(L.total_pieces) * kPieceBytes,
+    rc = launch_pack48(*desc, precision, ptrs, static_cast<char*>(packed) + L.bias_bytes + static_cast<size_t>(L.total_pieces) * kPieceBytes,
                        as_stream(stream));
   return rc;
 }

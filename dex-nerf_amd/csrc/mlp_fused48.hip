@@ -1,4 +1,4 @@
-// bf16 inference forward in the 48-points-per-wave geometry (see mlp_geo48.h): fused positional encoding +
+// bf16 / fp16 inference forward in the 48-points-per-wave geometry (see mlp_geo48.h): fused positional encoding +
 // FlexibleNeRFModel forward (reference run_network, nerf/train_utils.py:72-89; positional_encoding
 // nerf/nerf_helpers.py:115-159; FlexibleNeRFModel.forward nerf/models.py:233-256), same design as mlp_fused.hip -
 // persistent workgroups, register-resident activation chain, LDS-DMA weight ring (Pipe<8>) - on
@@ -15,11 +15,15 @@
 
 namespace dn {
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
+// F = 1: bf16, 2: fp16 (Prec<F> of mlp_device.h): same MFMA rate and layouts
+template <int F>
+__device__ __forceinline__ f32x4 mfma48(typename Prec<F>::BPiece a, typename Prec<F>::BPiece b, f32x4 c) {
+  if constexpr (F == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 
 // One GEMM stage: NT_OUT 16-row output tiles, KH hidden pieces + KP encoding pieces per tile, three point groups.
-template <int NT_OUT, int KH, int KP, int POS0, class PipeT, class BH, class BP, class Emit>
+template <int F, int NT_OUT, int KH, int KP, int POS0, class PipeT, class BH, class BP, class Emit>
 __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, const char* bias_g, Emit&& emit) {
   constexpr int PT = 3, KT = KH + KP;
   static_for<NT_OUT>([&](auto nt_c) {
@@ -33,11 +37,11 @@ __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, 
       constexpr int pos = POS0 + nt * KT + k;
       if constexpr (pos % kPhasePieces == 0) pipe.phase_begin();
       if constexpr (pos % kPhasePieces == kPhasePieces / 2) pipe.mid_phase();
-      const bf16x8 a = __builtin_bit_cast(bf16x8, pipe.af[pos % kPrefetch]);
+      const auto a = __builtin_bit_cast(typename Prec<F>::BPiece, pipe.af[pos % kPrefetch]);
       static_for<PT>([&](auto t_c) {
         constexpr int t = decltype(t_c)::value;
-        if constexpr (k < KH) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh[t][k], acc[t], 0, 0, 0);
-        else acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bp(t, k - KH), acc[t], 0, 0, 0);
+        if constexpr (k < KH) acc[t] = mfma48<F>(a, bh[t][k], acc[t]);
+        else acc[t] = mfma48<F>(a, bp(t, k - KH), acc[t]);
       });
       pipe.template prefetch<pos>();
       __builtin_amdgcn_sched_group_barrier(0x008, PT, 0);
@@ -49,26 +53,26 @@ __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, 
 }
 
 // rows 4g..4g+3 of output tile NT -> elements (NT & 1) * 4 .. + 3 of B piece NT / 2 (g48_hidden_col)
-template <bool RELU, int NT, class BO>
+template <int F, bool RELU, int NT, class BO>
 __device__ __forceinline__ void emit48(const f32x4& acc, BO& bo) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef typename Prec<F>::Elem e16x2 __attribute__((ext_vector_type(2)));
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   u32x4 w = __builtin_bit_cast(u32x4, bo[NT / 2]);
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
     const f32x2 f = {acc[2 * d], acc[2 * d + 1]};
-    bf16x2 v = __builtin_convertvector(f, bf16x2);  // one v_cvt_pk_bf16_f32
-    if constexpr (RELU) {  // a negative bf16 is a negative int16 (mlp_device.h make_piece)
+    e16x2 v = __builtin_convertvector(f, e16x2);  // one packed convert
+    if constexpr (RELU) {  // a negative bf16 / fp16 is a negative int16 (mlp_device.h make_piece)
       s16x2 bits = __builtin_bit_cast(s16x2, v);
       const s16x2 zero = {0, 0};
       bits = __builtin_elementwise_max(bits, zero);
-      v = __builtin_bit_cast(bf16x2, bits);
+      v = __builtin_bit_cast(e16x2, bits);
     }
     w[(NT & 1) * 2 + d] = __builtin_bit_cast(unsigned, v);
   }
-  bo[NT / 2] = __builtin_bit_cast(bf16x8, w);
+  bo[NT / 2] = __builtin_bit_cast(typename Prec<F>::BPiece, w);
 }
 
 // one encoding slot: table entry = (frequency, phase in revolutions, identity weight, sine weight); the coordinate is a
@@ -93,8 +97,10 @@ __device__ __forceinline__ void rotate3(const float (&x)[3], int g, float (&xr)[
   xr[2] = __uint_as_float(b2 ^ ((b2 ^ b0) & m1) ^ ((b2 ^ b1) & m2));
 }
 
-template <int W>
+template <int W, int F>
 __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdParams p, G48Params q) {
+  using BP8 = typename Prec<F>::BPiece;
+  using Elem = typename Prec<F>::Elem;
   constexpr int PT = 3;
   constexpr int NT = W / 16;
   constexpr int KH = W / 32;
@@ -211,31 +217,31 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         rotate3(x, ln >> 4, xr);
 #pragma unroll
         for (int k = 0; k < KXP; ++k) {
-          bf16x8 piece;
+          BP8 piece;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) piece[e] = static_cast<__bf16>(pe_value(xr[(k * 8 + e) % 3], tabx[k * 8 + e]));
-          *reinterpret_cast<bf16x8*>(pex + (t * KXP + k) * kPieceBytes) = piece;
+          for (int e = 0; e < 8; ++e) piece[e] = static_cast<Elem>(pe_value(xr[(k * 8 + e) % 3], tabx[k * 8 + e]));
+          *reinterpret_cast<BP8*>(pex + (t * KXP + k) * kPieceBytes) = piece;
         }
       }
     }
-    auto pe_xyz = [&](int t, int k) { return *reinterpret_cast<const bf16x8*>(pex_of(pipe.lane16 >> 4) + (t * KXP + k) * kPieceBytes); };
-    auto no_pe = [&](int, int) { return bf16x8{}; };
+    auto pe_xyz = [&](int t, int k) { return *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + (t * KXP + k) * kPieceBytes); };
+    auto no_pe = [&](int, int) { return BP8{}; };
 
-    bf16x8 ba[PT][KH], bb[PT][KH];
-    bf16x8 none[PT][1];
+    BP8 ba[PT][KH], bb[PT][KH];
+    BP8 none[PT][1];
     int bias_tile = 0;
     // ---- layer1: xyz encoding -> W, no activation (models.py:238) ----
-    run_stage48<NT, 0, KXP, 0>(pipe, none, pe_xyz, bias_g, [&](auto nt_c, auto t_c, const f32x4& acc) {
-      emit48<false, decltype(nt_c)::value>(acc, ba[decltype(t_c)::value]);
+    run_stage48<F, NT, 0, KXP, 0>(pipe, none, pe_xyz, bias_g, [&](auto nt_c, auto t_c, const f32x4& acc) {
+      emit48<F, false, decltype(nt_c)::value>(acc, ba[decltype(t_c)::value]);
     });
     bias_tile += NT;
     // ---- trunk (models.py:239-246), two layers per iteration: the activations ping-pong between two register sets ----
-    auto trunk_layer = [&](int i, const bf16x8 (&bin)[PT][KH], bf16x8 (&bout)[PT][KH]) __attribute__((always_inline)) {
+    auto trunk_layer = [&](int i, const BP8 (&bin)[PT][KH], BP8 (&bout)[PT][KH]) __attribute__((always_inline)) {
       auto emit = [&](auto nt_c, auto t_c, const f32x4& acc) {
-        emit48<true, decltype(nt_c)::value>(acc, bout[decltype(t_c)::value]);
+        emit48<F, true, decltype(nt_c)::value>(acc, bout[decltype(t_c)::value]);
       };
-      if ((p.skip_mask >> i) & 1u) run_stage48<NT, KH, KXP, 0>(pipe, bin, pe_xyz, bias_g + bias_tile * 64, emit);
-      else run_stage48<NT, KH, 0, 0>(pipe, bin, no_pe, bias_g + bias_tile * 64, emit);
+      if ((p.skip_mask >> i) & 1u) run_stage48<F, NT, KH, KXP, 0>(pipe, bin, pe_xyz, bias_g + bias_tile * 64, emit);
+      else run_stage48<F, NT, KH, 0, 0>(pipe, bin, no_pe, bias_g + bias_tile * 64, emit);
       bias_tile += NT;
     };
     int i = 0;
@@ -253,11 +259,11 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     float out4[PT][4];
     if (p.use_viewdirs) {
       // ---- fc_alpha (its own 16-row tile, row 0, streamed first) + fc_feat with ReLU (models.py:248-249) ----
-      run_stage48<1, KH, 0, 0>(pipe, ba, no_pe, bias_g + bias_tile * 64, [&](auto, auto t_c, const f32x4& acc) {
+      run_stage48<F, 1, KH, 0, 0>(pipe, ba, no_pe, bias_g + bias_tile * 64, [&](auto, auto t_c, const f32x4& acc) {
         out4[decltype(t_c)::value][3] = acc[0];  // row 0 lives in lane group 0, register 0
       });
-      run_stage48<NT, KH, 0, KH % kPhasePieces>(pipe, ba, no_pe, bias_g + (bias_tile + 1) * 64, [&](auto nt_c, auto t_c, const f32x4& acc) {
-        emit48<true, decltype(nt_c)::value>(acc, bb[decltype(t_c)::value]);
+      run_stage48<F, NT, KH, 0, KH % kPhasePieces>(pipe, ba, no_pe, bias_g + (bias_tile + 1) * 64, [&](auto nt_c, auto t_c, const f32x4& acc) {
+        emit48<F, true, decltype(nt_c)::value>(acc, bb[decltype(t_c)::value]);
       });
       bias_tile += NT + 1;
       // ---- view-direction encoding (one 32-deep piece per point group) ----
@@ -277,25 +283,25 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
           for (int c = 0; c < 3; ++c) v[c] = inbuf[(7 + 3 * vset + c) * PPW + t * 16 + j];
           float vr[3];
           rotate3(v, ln >> 4, vr);
-          bf16x8 piece;
+          BP8 piece;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) piece[e] = static_cast<__bf16>(pe_value(vr[e % 3], tabd[e]));
-          *reinterpret_cast<bf16x8*>(pex + t * kPieceBytes) = piece;
+          for (int e = 0; e < 8; ++e) piece[e] = static_cast<Elem>(pe_value(vr[e % 3], tabd[e]));
+          *reinterpret_cast<BP8*>(pex + t * kPieceBytes) = piece;
           __builtin_amdgcn_sched_barrier(0);
         });
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- layers_dir[0] on cat(feat, view) -> W/2, ReLU (models.py:250-252) ----
       constexpr int POS_D = ((NT + 1) * KH) % kPhasePieces;
-      bf16x8 bg[PT][KH / 2];
-      auto pe_dir = [&](int t, int) { return *reinterpret_cast<const bf16x8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes); };
-      run_stage48<NT / 2, KH, KDP, POS_D>(pipe, bb, pe_dir, bias_g + bias_tile * 64, [&](auto nt_c, auto t_c, const f32x4& acc) {
-        emit48<true, decltype(nt_c)::value>(acc, bg[decltype(t_c)::value]);
+      BP8 bg[PT][KH / 2];
+      auto pe_dir = [&](int t, int) { return *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes); };
+      run_stage48<F, NT / 2, KH, KDP, POS_D>(pipe, bb, pe_dir, bias_g + bias_tile * 64, [&](auto nt_c, auto t_c, const f32x4& acc) {
+        emit48<F, true, decltype(nt_c)::value>(acc, bg[decltype(t_c)::value]);
       });
       bias_tile += NT / 2;
       // ---- fc_rgb (models.py:253) ----
       constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % kPhasePieces;
-      run_stage48<1, KH / 2, 0, POS_R>(pipe, bg, no_pe, bias_g + bias_tile * 64, [&](auto, auto t_c, const f32x4& acc) {
+      run_stage48<F, 1, KH / 2, 0, POS_R>(pipe, bg, no_pe, bias_g + bias_tile * 64, [&](auto, auto t_c, const f32x4& acc) {
         constexpr int t = decltype(t_c)::value;
         out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2];
       });
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       if constexpr (END % kPhasePieces != 0) pipe.template skip<END, kPhasePieces - END>();
     } else {
       // ---- fc_out (models.py:256) ----
-      run_stage48<1, KH, 0, 0>(pipe, ba, no_pe, bias_g + bias_tile * 64, [&](auto, auto t_c, const f32x4& acc) {
+      run_stage48<F, 1, KH, 0, 0>(pipe, ba, no_pe, bias_g + bias_tile * 64, [&](auto, auto t_c, const f32x4& acc) {
         constexpr int t = decltype(t_c)::value;
         out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2]; out4[t][3] = acc[3];
       });
@@ -325,7 +331,9 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 }
 
 // ---- pack: nn.Linear tensors -> bias rows + encoding tables + 16x32 A pieces -----------------------------------
+template <int F>
 __global__ void pack48_kernel(NetLayout L, PackPtrs ptrs, G48Tables tabs, char* __restrict__ region) {
+  using Elem = typename Prec<F>::Elem;
   const int n_rows = L.total_bias_tiles * 16;
   float* bias_out = reinterpret_cast<float*>(region);
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < L.bias_bytes / 4; idx += gridDim.x * blockDim.x) {
@@ -363,7 +371,7 @@ __global__ void pack48_kernel(NetLayout L, PackPtrs ptrs, G48Tables tabs, char* 
     tab[idx] = entry;
   }
   // pieces
-  __bf16* wout = reinterpret_cast<__bf16*>(region + L.bias_bytes + kG48TableBytes);
+  Elem* wout = reinterpret_cast<Elem*>(region + L.bias_bytes + kG48TableBytes);
   const long long n_elems = static_cast<long long>(L.total_pieces) * 64 * 8;
   for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < n_elems;
        idx += static_cast<long long>(gridDim.x) * blockDim.x) {
@@ -397,24 +405,25 @@ __global__ void pack48_kernel(NetLayout L, PackPtrs ptrs, G48Tables tabs, char* 
         }
       }
     }
-    wout[idx] = static_cast<__bf16>(v);
+    wout[idx] = static_cast<Elem>(v);
   }
 }
 
 void fill_freqs(float* f, int num_fns, int log_sampling);  // rays_sampling.hip
 
-int launch_pack48(const dn_mlp_desc& d, const PackPtrs& ptrs, char* region, hipStream_t stream) {
+int launch_pack48(const dn_mlp_desc& d, int precision, const PackPtrs& ptrs, char* region, hipStream_t stream) {
   NetLayout L;
   build_layout48(d, &L);
   G48Tables tabs{};
   fill_freqs(tabs.fx, d.num_encoding_fn_xyz, d.log_sampling_xyz);
   if (d.use_viewdirs) fill_freqs(tabs.fd, d.num_encoding_fn_dir, d.log_sampling_dir);
   tabs.LX = d.num_encoding_fn_xyz; tabs.LD = d.num_encoding_fn_dir;
-  hipLaunchKernelGGL(pack48_kernel, dim3(512), dim3(256), 0, stream, L, ptrs, tabs, region);
+  if (precision == DN_PREC_F16) hipLaunchKernelGGL(pack48_kernel<2>, dim3(512), dim3(256), 0, stream, L, ptrs, tabs, region);
+  else hipLaunchKernelGGL(pack48_kernel<1>, dim3(512), dim3(256), 0, stream, L, ptrs, tabs, region);
   return check_launch("mlp_pack48");
 }
 
-int launch_forward48(const dn_mlp_desc& d, const FwdParams& p_in, const char* region, hipStream_t stream) {
+int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in, const char* region, hipStream_t stream) {
   NetLayout L;
   build_layout48(d, &L);
   FwdParams p = p_in;
@@ -434,9 +443,10 @@ int launch_forward48(const dn_mlp_desc& d, const FwdParams& p_in, const char* re
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(kG48Waves * 64), lds, stream, p, q);
     return check_launch("mlp_forward48");
   };
-  static thread_local bool attr256 = false, attr128 = false;
-  if (d.hidden_size == 256) return launch(mlp_forward48_kernel<256>, attr256);
-  return launch(mlp_forward48_kernel<128>, attr128);
+  static thread_local bool attr[4] = {false, false, false, false};
+  if (precision == DN_PREC_F16)
+    return d.hidden_size == 256 ? launch(mlp_forward48_kernel<256, 2>, attr[2]) : launch(mlp_forward48_kernel<128, 2>, attr[3]);
+  return d.hidden_size == 256 ? launch(mlp_forward48_kernel<256, 1>, attr[0]) : launch(mlp_forward48_kernel<128, 1>, attr[1]);
 }
 
 }  // namespace dn

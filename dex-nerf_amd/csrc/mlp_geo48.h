@@ -97,9 +97,9 @@ inline size_t g48_lds_bytes(const NetLayout& L) {
          kG48Waves * kG48InRows * kG48PointsPerWave * sizeof(float);
 }
 
-// bf16 nets whose bias rows leave room for the stash in 160 KiB of LDS (W = 256: D <= 9 with view directions)
+// bf16 / fp16 nets whose bias rows leave room for the stash in 160 KiB of LDS (W = 256: D <= 9 with view directions)
 inline bool g48_supported(const dn_mlp_desc& d, int precision) {
-  if (precision != DN_PREC_BF16 || (d.hidden_size != 256 && d.hidden_size != 128)) return false;
+  if ((precision != DN_PREC_BF16 && precision != DN_PREC_F16) || (d.hidden_size != 256 && d.hidden_size != 128)) return false;
   NetLayout L;
   build_layout48(d, &L);
   return g48_lds_bytes(L) <= 160 * 1024;
@@ -111,7 +111,7 @@ inline size_t g48_region_bytes(const dn_mlp_desc& d) {
   return static_cast<size_t>(L.bias_bytes) + kG48TableBytes + static_cast<size_t>(L.total_pieces) * kPieceBytes;
 }
 
-int launch_pack48(const dn_mlp_desc& d, const PackPtrs& ptrs, char* region, hipStream_t stream);
-int launch_forward48(const dn_mlp_desc& d, const FwdParams& p, const char* region, hipStream_t stream);
+int launch_pack48(const dn_mlp_desc& d, int precision, const PackPtrs& ptrs, char* region, hipStream_t stream);
+int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p, const char* region, hipStream_t stream);
 
 }  // namespace dn

@@ -995,8 +995,9 @@ def test_fp32_weight_grad_kernel_against_unpacked_gemms(dev):
             assert rel_err(C(d_b), C(dy.sum(0))) < 2e-5, (kw, mod)
 
 
-def test_bf16_48_point_geometry_against_32_point_and_fp32(dev, monkeypatch):
-    """The 48-points-per-wave bf16 inference kernel (mlp_fused48.hip, the default for W=256) against the 32-point bf16
+@pytest.mark.parametrize("prec16", ["bf16", "fp16"])
+def test_48_point_geometry_against_32_point_and_fp32(dev, monkeypatch, prec16):
+    """The 48-points-per-wave bf16 / fp16 inference kernel (mlp_fused48.hip, the default) against the 32-point 16-bit
     kernel (DEXNERF_BF16_GEOM=32: same products, different fp32 accumulation grouping and cosine phase form) and against
     the exact-fp32 kernel, on ragged point counts around the 384-point workgroup tile, both input forms, with / without
     view directions, odd / even trunk depth, skip at different layers.  The two bf16 kernels form the same products and
@@ -1012,7 +1013,7 @@ def test_bf16_48_point_geometry_against_32_point_and_fp32(dev, monkeypatch):
         kw = dict(num_layers=D, hidden_size=width, skip_connect_every=skip, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=view)
         sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(11 + D, sigma_gain=5.0, sigma_bias=0.0, **kw).items()}
         packed = {}
-        for prec in ("fp32", "bf16"):
+        for prec in ("fp32", prec16):
             nerf.set_precision(prec)
             m = nerf.models.FlexibleNeRFModel(**kw); m.load_state_dict(sd); m = m.to(dev)
             packed[prec] = (m, m.packed())
@@ -1031,9 +1032,9 @@ def test_bf16_48_point_geometry_against_32_point_and_fp32(dev, monkeypatch):
                         return _ops.run_network_rays(pk, rays, z)
                 ref = run("fp32")
                 monkeypatch.setenv("DEXNERF_BF16_GEOM", "32")
-                o32 = run("bf16")
+                o32 = run(prec16)
                 monkeypatch.delenv("DEXNERF_BF16_GEOM")
-                o48 = run("bf16")
+                o48 = run(prec16)
                 scale = float(ref.abs().max()) + 1e-6
                 case = (width, D, view, skip, n_rays, s, form)
                 assert torch.isfinite(o48).all(), case
@@ -1048,7 +1049,7 @@ def test_bf16_48_point_geometry_against_32_point_and_fp32(dev, monkeypatch):
     # a D the 48-point kernel's LDS budget excludes falls back to the 32-point kernel transparently (D = 12 here)
     kw = dict(num_layers=12, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
     sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(3, sigma_gain=5.0, sigma_bias=0.0, **kw).items()}
-    nerf.set_precision("bf16")
+    nerf.set_precision(prec16)
     try:
         m = nerf.models.FlexibleNeRFModel(**kw); m.load_state_dict(sd); m = m.to(dev)
         pts = torch.randn(500, 3, device=dev)

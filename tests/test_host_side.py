@@ -39,10 +39,10 @@ def test_argument_validation_needs_no_gpu(hiplib):
                      num_encoding_fn_dir=4, include_input_xyz=1, include_input_dir=1, use_viewdirs=1,
                      log_sampling_xyz=1, log_sampling_dir=1)
     # D8/W256: bias tiles (8 + 7*8 + 9 + 4 + 1) = 78 -> 10 KiB; pieces 1184 (bf16) / 2368 (fp32) KiB
-    # bf16 W=256 nets carry a second stream for the 48-points-per-wave inference kernel: 2464 bias rows -> 10 KiB,
+    # bf16 / fp16 nets carry a second stream for the 48-points-per-wave inference kernel: 2464 bias rows -> 10 KiB,
     # 1.5 KiB of encoding tables, 1184 pieces of 16 x 32
     assert hiplib.dn_mlp_packed_bytes(ctypes.byref(d), _hip.PREC_BF16) == (10 + 1184) * 1024 + (10 + 1184) * 1024 + 1536
-    assert hiplib.dn_mlp_packed_bytes(ctypes.byref(d), _hip.PREC_F16) == 10 * 1024 + 1184 * 1024
+    assert hiplib.dn_mlp_packed_bytes(ctypes.byref(d), _hip.PREC_F16) == hiplib.dn_mlp_packed_bytes(ctypes.byref(d), _hip.PREC_BF16)
     assert hiplib.dn_mlp_packed_bytes(ctypes.byref(d), _hip.PREC_F32) == 10 * 1024 + 2368 * 1024
     d.hidden_size = 192
     assert hiplib.dn_mlp_packed_bytes(ctypes.byref(d), _hip.PREC_BF16) == 0

@@ -262,7 +262,7 @@ def main():
                        "rays_per_step_per_gpu": H * W, "sharding": f"{world} ranks x own view (no collective in the path)"},
             "roofline": {"bound": "mfma", "achieved": ktf, "peak": peak, "unit": "TFLOP/s", "frac": ktf / peak,
                          "traffic": pmc_traffic(args.precision), "traffic_estimate": pmc_traffic_estimate(args.precision),
-                         "kernel": ("mlp_forward48_kernel<256>" if geometry48(args.precision) else "mlp_forward_kernel<256,10,4>") + " (fine net, 160000x192 points)",
+                         "kernel": ("mlp_forward48_kernel<256,1>" if geometry48(args.precision) else "mlp_forward_kernel<256,10,4>") + " (fine net, 160000x192 points)",
                          "kernel_ms": kt * 1e3, "whole_path_tflops": whole_tf},
         }
         if world > 1:

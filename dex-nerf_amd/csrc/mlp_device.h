@@ -178,6 +178,12 @@ struct Pipe {
     q_issue += kSlotBytes;
     if (q_issue >= total_bytes) q_issue = 0;
     slot_wr = (slot_wr + 1 == kRingPhases) ? 0 : slot_wr + 1;
+#ifdef DN_PIPE_SCALAR_STATE  // pin the (wave-uniform) ring state to SGPRs: hipcc otherwise keeps it in ~8 VGPRs (mlp_fused48.hip: 8 -> 0 spills)
+    q_issue = __builtin_amdgcn_readfirstlane(q_issue);
+    slot_wr = __builtin_amdgcn_readfirstlane(slot_wr);
+    pend_src = __builtin_amdgcn_readfirstlane(pend_src);
+    pend_dst = __builtin_amdgcn_readfirstlane(pend_dst);
+#endif
   }
 
   __device__ __forceinline__ void issue_phase() {  // prologue only

@@ -1,12 +1,13 @@
 #!/bin/bash
 # Developer tool (run on the GPU box): cycles vs wall time of the fine-net launch for ablation builds of the library.
-#   scripts/pmc_ablate.sh base nodma noread      (exp_libs/lib<NAME>.so; "base" = the shipped library)
+#   scripts/pmc_ablate.sh base geom32 nodma noread   (exp_libs/lib<NAME>.so; "base" = the shipped library, geom32 / pt2 = its other geometries)
 # Answers whether an ablation saves GPU cycles (pipeline effect) or only wall time (clock / power effect).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 for tag in "$@"; do
-  unset DEXNERF_HIP_LIB DEXNERF_BF16_PT
+  unset DEXNERF_HIP_LIB DEXNERF_BF16_PT DEXNERF_BF16_GEOM
   if [ "$tag" = pt2 ]; then export DEXNERF_BF16_PT=2   # shipped library, 4 waves x 64 points
+  elif [ "$tag" = geom32 ]; then export DEXNERF_BF16_GEOM=32   # shipped library, the 32-point kernel
   elif [ "$tag" != base ]; then export DEXNERF_HIP_LIB=exp_libs/lib$tag.so; fi
   rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv \
       -d gpurun_out/abl_$tag -- python3 scripts/quick_time.py bf16 160000 > gpurun_out/abl_$tag.log 2>&1 || { echo "$tag: profiler run failed"; tail -3 gpurun_out/abl_$tag.log; exit 1; }

@@ -93,22 +93,14 @@ def geometry48(precision):
     return precision == "bf16" and os.environ.get("DEXNERF_BF16_GEOM", "") != "32"
 
 
-def pmc_traffic(precision):
-    """HBM bytes per fine-net launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE, profiles/r01_pmc_fine_net.json); bench.py itself cannot run the profiler.  That pass exists for the
-    32-point kernel only (it no longer completes on this pool): null for the 48-point kernel, whose estimate from the
-    L2-miss count is reported beside it as `traffic_estimate`."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_fine_net.json")
-    if precision != "bf16" or not os.path.exists(path) or geometry48(precision):
-        return None
-    return json.load(open(path))["hbm_bytes_per_launch"]
-
-
-def pmc_traffic_estimate(precision):
-    path = os.path.join(REPO, "profiles", "r01_pmc_fine_net.json")
+def pmc_record(precision):
+    """The committed rocprofv3 --pmc passes on this exact launch (scripts/pmc_fine_net.sh -> profiles/r02_pmc_fine_net.json:
+    FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes, FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md).  bench.py itself cannot run the profiler; the record is for the 48-point bf16 kernel."""
+    path = os.path.join(REPO, "profiles", "r02_pmc_fine_net.json")
     if not geometry48(precision) or not os.path.exists(path):
-        return None
-    return json.load(open(path)).get("g48_build", {}).get("hbm_bytes_per_launch_estimate")
+        return {}
+    return json.load(open(path)).get("derived", {})
 
 
 def library_gemm_tflops(dev, precision):
@@ -129,19 +121,26 @@ def library_gemm_tflops(dev, precision):
     return {"shape": f"{m}^3 {precision}", "tflops": 2.0 * m ** 3 * 10 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12}
 
 
-def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8):
+def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pose_id=7):
     """Secondary metric (SURVEY.md section 8d ii): rays/s of a full training iteration (perturbed sampling, density
-    noise, forward + backward + Adam) on n_rays random rays of the view."""
+    noise, forward + backward + Adam) on n_rays random rays of this rank's view.  With `dist` (N > 1) it is the data-parallel
+    step north_star names (reference loop: train_dexnerf_rgb.py:264-289): every rank its own rays, the gradients of both nets
+    averaged over RCCL (one message per network, the fine one overlapped with the coarse backward - nerf/parallel.py), identical
+    fused Adam on every rank; barrier + max-over-ranks timing like the headline."""
     import nerf
+    from nerf import _hip, _ops, parallel
     dev = ro.device
+    world = dist.get_world_size() if dist is not None else 1
     cfg.nerf.train.perturb = True
     cfg.nerf.train.radiance_field_noise_std = 0.2
     cfg.nerf.train.chunksize = n_rays
-    params = list(models[0].parameters()) + list(models[1].parameters())
-    opt = torch.optim.Adam(params, lr=5e-4, fused=True)  # one multi-tensor kernel instead of seven
+    if dist is not None:
+        parallel.broadcast_parameters(models)
+    bucket = parallel.FlatGradBucket(models)
+    opt = torch.optim.Adam(bucket.params, lr=5e-4, fused=True)  # one multi-tensor kernel instead of seven
     from nerf import synthetic as syn
     image = torch.rand(H, W, 3, device=dev)
-    selector = nerf.RaySelector(H, W, torch.from_numpy(syn.scene_pose(7)), torch.from_numpy(syn.intrinsic(H, W)), 2.0, 6.0, device=dev)
+    selector = nerf.RaySelector(H, W, torch.from_numpy(syn.scene_pose(pose_id)), torch.from_numpy(syn.intrinsic(H, W)), 2.0, 6.0, device=dev)
 
     def step():
         # pixel draw -> packed ray rows + target pixels in one kernel, then the reference's per-chunk entry point
@@ -149,19 +148,69 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8):
         out = nerf.predict_and_render_radiance(rays, models[0], models[1], cfg, mode="train", encode_position_fn=ex,
                                                encode_direction_fn=ed, m_thres_cand=M_THRES)
         loss = nerf.img2mse(out[0], target) + nerf.img2mse(out[3], target)
-        opt.zero_grad(set_to_none=True)
+        bucket.zero()
         loss.backward()
+        bucket.all_reduce_mean()
         opt.step()
     for _ in range(3):
         step()
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     dt = (time.perf_counter() - t0) / steps
-    return {"rays_per_s": n_rays / dt, "ms_per_step": dt * 1e3, "rays_per_step": n_rays,
-            "what": "ray selection + fwd + bwd + fused Adam, 64+128 samples, perturb + noise 0.2, D8/W256 x2, fused HIP training kernels"}
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    res = {"rays_per_s": world * n_rays / dt, "ms_per_step": dt * 1e3, "rays_per_step_per_gpu": n_rays, "n_gpus": world,
+           "what": "ray selection + fwd + bwd + fused Adam, 64+128 samples, perturb + noise 0.2, D8/W256 x2, fused HIP training kernels"}
+    # roofline of the step: HBM-bound by construction - the saved activations and gradients are written
+    # once by the forward / backward chains and read once by the weight-gradient kernel; MFMA rate beside it (3x forward FLOP)
+    prec = _hip.PREC_BF16 if nerf.get_precision() == "bf16" else _hip.PREC_F32
+    nbytes = 0
+    for m, s in ((models[0], NC), (models[1], NC + NF)):
+        a, mk, g = _ops.train_sizes(m.packed(), n_rays * s)
+        nbytes += 2 * (a + g) + 2 * mk + n_rays * s * (16 + 16 + 4) * 2   # + rf / g_rf / z through compositing
+    flops = 3.0 * n_rays * POINTS_PER_RAY * FLOP_PER_POINT
+    res["roofline"] = {"bound": "hbm", "achieved": nbytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / dt / 8e12,
+                       "bytes_per_step": nbytes, "mfma_tflops": flops / dt / 1e12,
+                       "mfma_frac": flops / dt / 1e12 / PEAK_TFLOPS[nerf.get_precision()],
+                       "what": "algorithmic bytes per step per GPU = 2 x (saved activations + saved gradients) + 2 x ReLU masks "
+                               "(dn_mlp_train_sizes, both nets) + the radiance-field tensors through compositing; whole step time"}
+    if dist is not None:
+        # the exchange alone: both segments, back to back, nothing to overlap with
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for _ in range(3):
+            dist.all_reduce(bucket.segment(1)); dist.all_reduce(bucket.segment(0))
+        torch.cuda.synchronize()
+        evs[0].record()
+        for _ in range(10):
+            dist.all_reduce(bucket.segment(1)); dist.all_reduce(bucket.segment(0))
+        evs[1].record()
+        torch.cuda.synchronize()
+        res["allreduce_ms"] = evs[0].elapsed_time(evs[1]) / 10
+        res["allreduce_bytes"] = int(bucket.flat.numel() * 4)
+        res["rccl_ranks"] = world
+        res["what"] += "; data-parallel: per-network RCCL all-reduce (fine overlapped with the coarse backward) + div, every rank its own rays"
+    return res
+
+
+def dex_agreement(out, ref, sel, dev):
+    """Dex-NeRF fixed-sigma depth readout (reference nerf/volume_rendering_utils.py:51-58) of this render against the fp32 CPU
+    oracle on the sampled rays: fraction of (threshold, ray) entries within 1e-4 of the depth range's maximum, and the worst
+    miss in metres (the readout is a thresholded first crossing: one flipped sample moves it by a sample spacing or more)."""
+    idx = torch.from_numpy(sel).to(dev)
+    mine = np.stack([o.reshape(-1)[idx].cpu().numpy() for o in out[6:]]).astype(np.float64)
+    theirs = np.stack([o.numpy() for o in ref[6:]]).astype(np.float64)
+    miss = np.abs(mine - theirs)
+    return {"agree_frac": float((miss <= 1e-4 * np.abs(theirs).max()).mean()), "worst_miss_m": float(miss.max()),
+            "mean_miss_m": float(miss.mean()), "entries": int(miss.size)}
 
 
 def cpu_baseline(sample_rays=16384):
@@ -212,6 +261,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus} but the RCCL process group has {dist.get_world_size()} ranks")
 
     import nerf
     from nerf import _hip
@@ -245,6 +296,11 @@ def main():
     value = rays_total / elapsed
 
     note(f"timed region: {elapsed:.3f} s for {args.steps} steps")
+    train_dp = None
+    if world > 1 and not args.no_train:
+        # the data-parallel training step (BASELINE configs 4 / 5 are training configs): collective inside, so every rank runs it
+        train_dp = train_rate(models, cfg, ro, rd, ex, ed, dist=dist, pose_id=7 + rank)
+        note(f"data-parallel training step: {train_dp['ms_per_step']:.2f} ms, all-reduce alone {train_dp['allreduce_ms']:.3f} ms")
     result = None
     if rank == 0:
         kt, ktf = time_dominant_kernel(models, ro, rd, args.precision)
@@ -261,10 +317,14 @@ def main():
                                    "validation mode (det. resampling, no noise)",
                        "rays_per_step_per_gpu": H * W, "sharding": f"{world} ranks x own view (no collective in the path)"},
             "roofline": {"bound": "mfma", "achieved": ktf, "peak": peak, "unit": "TFLOP/s", "frac": ktf / peak,
-                         "traffic": pmc_traffic(args.precision), "traffic_estimate": pmc_traffic_estimate(args.precision),
+                         "traffic": pmc_record(args.precision).get("hbm_bytes_per_launch"),
+                         "algorithmic_bytes": H * W * (NC + NF) * 20 + H * W * 44,
+                         "matrix_pipe_busy_frac_pmc": pmc_record(args.precision).get("matrix_pipe_busy_frac"),
                          "kernel": ("mlp_forward48_kernel<256,1>" if geometry48(args.precision) else "mlp_forward_kernel<256,10,4>") + " (fine net, 160000x192 points)",
                          "kernel_ms": kt * 1e3, "whole_path_tflops": whole_tf},
         }
+        if train_dp is not None:
+            result["train_dp"] = train_dp
         if world > 1:
             args.no_cpu_baseline = True   # the CPU baseline is reported at N=1 only
         if not args.no_cpu_baseline:
@@ -273,6 +333,7 @@ def main():
             rgb = out[3].reshape(-1, 3)[torch.from_numpy(sel).to(dev)].cpu().numpy()
             mse = float(np.mean((rgb - ref[3].numpy()) ** 2))
             result["psnr_vs_oracle_db"] = float(-10.0 * np.log10(max(mse, 1e-12)))
+            result["dex_vs_oracle"] = dex_agreement(out, ref, sel, dev)
             result["gpu_over_cpu"] = value / world / cb["value"]
         if args.precision == "bf16" and not args.no_cpu_baseline:
             # the same render in the fp16 MFMA mode (same matrix rate, 10-bit mantissa): informational
@@ -287,8 +348,28 @@ def main():
             rgb16 = out16[3].reshape(-1, 3)[torch.from_numpy(sel).to(dev)].cpu().numpy()
             mse16 = float(np.mean((rgb16 - ref[3].numpy()) ** 2))
             result["fp16_mode"] = {"value": H * W / dt16, "unit": "rays/s",
-                                   "psnr_vs_oracle_db": float(-10.0 * np.log10(max(mse16, 1e-12)))}
+                                   "psnr_vs_oracle_db": float(-10.0 * np.log10(max(mse16, 1e-12))),
+                                   "dex_vs_oracle": dex_agreement(out16, ref, sel, dev)}
             nerf.set_precision(args.precision)
+        if args.precision == "bf16" and not args.no_cpu_baseline:
+            # the same render in the exact-fp32 parity mode (north_star's 1e-4 tolerance holds in this mode only): 3 steps
+            nerf.set_precision("fp32")
+            try:
+                render(models, cfg, ro, rd, ex, ed)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    out32 = render(models, cfg, ro, rd, ex, ed)
+                torch.cuda.synchronize()
+                dt32 = (time.perf_counter() - t1) / 3
+                kt32, ktf32 = time_dominant_kernel(models, ro, rd, "fp32", reps=2)
+                rgb32 = out32[3].reshape(-1, 3)[torch.from_numpy(sel).to(dev)].cpu().numpy()
+                err32 = float(np.abs(rgb32 - ref[3].numpy()).max() / np.abs(ref[3].numpy()).max())
+                result["fp32_mode"] = {"value": H * W / dt32, "unit": "rays/s", "kernel_ms": kt32 * 1e3, "tflops": ktf32,
+                                       "peak": PEAK_TFLOPS["fp32"], "frac": ktf32 / PEAK_TFLOPS["fp32"],
+                                       "rgb_fine_rel_err_vs_oracle": err32, "dex_vs_oracle": dex_agreement(out32, ref, sel, dev)}
+            finally:
+                nerf.set_precision(args.precision)
         if not args.no_train and world == 1:
             result["train"] = train_rate(models, cfg, ro, rd, ex, ed)
         if not args.no_train and world == 1 and args.precision == "bf16":

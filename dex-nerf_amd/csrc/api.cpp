@@ -1,6 +1,8 @@
 // Library-level entry points: error string, ABI version, and the fused predict_and_render_radiance
 // forward (reference nerf/train_utils.py:92-202) sequenced on one stream from the per-stage kernels.
 #include <cstring>
+#include <utility>
+#include <vector>
 
 #include "dn_common.h"
 
@@ -13,6 +15,31 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+int ensure_big_lds(const void* kernel) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  static thread_local std::vector<std::pair<const void*, int>> done;
+  for (const auto& kd : done)
+    if (kd.first == kernel && kd.second == dev) return 0;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute(device %d): %s", dev, hipGetErrorString(e)); return -static_cast<int>(e); }
+  done.emplace_back(kernel, dev);
+  return 0;
+}
+
+int device_cus() {
+  constexpr int kMaxDev = 64;
+  static thread_local int cache[kMaxDev] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+  if (cache[dev] == 0) {
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cache[dev] = cus;
+  }
+  return cache[dev];
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }

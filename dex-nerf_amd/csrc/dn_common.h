@@ -25,6 +25,13 @@ inline int check_launch(const char* what) {
   return 0;
 }
 
+// Per-device launch state (api.cpp).  hipFuncAttributeMaxDynamicSharedMemorySize is set per DEVICE: a flag per thread or per
+// template instance is not enough in a process that launches on a second GPU (tests, eval with LOCAL_RANK != first device).
+// ensure_big_lds() sets it once per (kernel, current device) per thread - setting it again from another thread is harmless -
+// and device_cus() caches the CU count of the current device, so the hot path makes one hipGetDevice call per launch.
+int ensure_big_lds(const void* kernel);   // 0 or -(hipError_t), error string set
+int device_cus();
+
 #define DN_REQUIRE(cond, ...)     \
   do {                            \
     if (!(cond)) {                \

@@ -7,6 +7,16 @@
 
 #include "mlp_layout.h"
 
+// The DN_EXP_* / DN_STORE_POLICY_ID hooks below are timing ablations (some of them knowingly UNSAFE: no cross-wave ordering,
+// loosened waits).  They compile only in an ablation build - scripts/build_exp.sh passes -DDN_ABLATION_BUILD, the Makefile
+// never does - so a stray -D cannot put one into the shipped library.
+#if !defined(DN_ABLATION_BUILD) && \
+    (defined(DN_EXP_NODMA) || defined(DN_EXP_NOREAD) || defined(DN_EXP_SHALLOW) || defined(DN_EXP_LOOSEWAIT) ||    \
+     defined(DN_EXP_NOBARRIER) || defined(DN_EXP_REGSTAGE) || defined(DN_EXP_ROTATE) || defined(DN_EXP_SETPRIO) || \
+     defined(DN_EXP_NOPIN) || defined(DN_EXP_NOSAVE) || defined(DN_STORE_POLICY_ID))
+#error "DN_EXP_* / DN_STORE_POLICY_ID are ablation hooks: build them with scripts/build_exp.sh (-DDN_ABLATION_BUILD), never into libdexnerf_hip.so"
+#endif
+
 namespace dn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

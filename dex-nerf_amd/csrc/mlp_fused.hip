@@ -454,15 +454,8 @@ static int launch_forward(FwdParams p, hipStream_t stream) {
   p.n_tiles = (p.n_points + PTS_PER_WG - 1) / PTS_PER_WG;
   constexpr int KDP = round_up(3 + 6 * LD, 16) / (2 * Prec<BF16>::EPP);
   const size_t lds = kRingBytes + p.bias_bytes + WAVES * (kInRows * 32 * PT * sizeof(float) + PT * (KXP + KDP) * kPieceBytes);
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -static_cast<int>(e); }
-    attr_set = true;
-  }
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  if (int rc = ensure_big_lds(reinterpret_cast<const void*>(kern))) return rc;
+  const int cus = device_cus();
   const long long grid = p.n_tiles < cus ? p.n_tiles : cus;
   hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(WAVES * 64), lds, stream, p);
   return check_launch("mlp_forward");

@@ -432,22 +432,16 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
   p.n_tiles = (p.n_points + kG48PointsPerWg - 1) / kG48PointsPerWg;
   const size_t lds = g48_lds_bytes(L);
   if (lds > 160 * 1024) { set_error("mlp_forward48: %zu bytes of LDS", lds); return DN_E_UNSUPPORTED; }
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  const int cus = device_cus();
   const long long grid = p.n_tiles < cus ? p.n_tiles : cus;
-  auto launch = [&](auto kern, bool& attr_set) -> int {
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -static_cast<int>(e); }
-      attr_set = true;
-    }
+  auto launch = [&](auto kern) -> int {
+    if (int rc = ensure_big_lds(reinterpret_cast<const void*>(kern))) return rc;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(kG48Waves * 64), lds, stream, p, q);
     return check_launch("mlp_forward48");
   };
-  static thread_local bool attr[4] = {false, false, false, false};
   if (precision == DN_PREC_F16)
-    return d.hidden_size == 256 ? launch(mlp_forward48_kernel<256, 2>, attr[2]) : launch(mlp_forward48_kernel<128, 2>, attr[3]);
-  return d.hidden_size == 256 ? launch(mlp_forward48_kernel<256, 1>, attr[0]) : launch(mlp_forward48_kernel<128, 1>, attr[1]);
+    return d.hidden_size == 256 ? launch(mlp_forward48_kernel<256, 2>) : launch(mlp_forward48_kernel<128, 2>);
+  return d.hidden_size == 256 ? launch(mlp_forward48_kernel<256, 1>) : launch(mlp_forward48_kernel<128, 1>);
 }
 
 }  // namespace dn

@@ -279,14 +279,8 @@ static int launch_backward(BwdParams p, hipStream_t stream) {
   auto kern = mlp_backward_kernel<W, BF16>;
   constexpr int WAVES = waves_of<BF16, 1>();
   p.n_tiles = (p.n_points + WAVES * 32 - 1) / (WAVES * 32);
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -static_cast<int>(e); }
-    attr_set = true;
-  }
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  if (int rc = ensure_big_lds(reinterpret_cast<const void*>(kern))) return rc;
+  const int cus = device_cus();
   const long long grid = p.n_tiles < cus ? p.n_tiles : cus;
   hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(WAVES * 64), kRingBytes + WAVES * kBwdWaveLds, stream, p);
   return check_launch("mlp_backward");
@@ -1019,17 +1013,7 @@ static int wg_fill(const dn_mlp_desc* desc, const TrainLayout& t, const void* ac
 }
 
 template <class K>
-static int wg_attr(K kern) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -static_cast<int>(e); }
-  return 0;
-}
-
-static int device_cus() {
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-  return cus;
-}
+static int wg_attr(K kern) { return ensure_big_lds(reinterpret_cast<const void*>(kern)); }
 
 }  // namespace dn
 
@@ -1105,12 +1089,7 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
     if (share[i] > tiles) share[i] = static_cast<int>(tiles);  // idle workgroups would exit at once anyway
     b.wg_begin[i + 1] = b.wg_begin[i] + share[i];
   }
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
-    if ((rc = wg_attr(weight_grad_batch_kernel))) return rc;
-    if ((rc = wg_attr(weight_grad_batch_kernel_f32))) return rc;
-    attr_set = true;
-  }
+  if ((rc = f32 ? wg_attr(weight_grad_batch_kernel_f32) : wg_attr(weight_grad_batch_kernel))) return rc;
   if (f32)
     hipLaunchKernelGGL(weight_grad_batch_kernel_f32, dim3(static_cast<unsigned>(b.wg_begin[n_units])), dim3(512), 158 * 1024,
                        as_stream(stream), b);
@@ -1132,11 +1111,7 @@ extern "C" int dn_mlp_weight_grad(const dn_mlp_desc* desc, int precision, const 
   build_train_layout(*desc, precision, &t);
   WgParams p{};
   if ((rc = wg_fill(desc, t, act, grads, n_points, g_slot, n_out, x_slot, x_width, pe_kind, dW, ldw, db, &p))) return rc;
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
-    if ((rc = wg_attr(weight_grad_kernel))) return rc;
-    attr_set = true;
-  }
+  if ((rc = wg_attr(weight_grad_kernel))) return rc;
   const int cus = device_cus();
   const long long tiles = (n_points + 31) / 32;
   const long long grid = tiles < cus ? tiles : cus;

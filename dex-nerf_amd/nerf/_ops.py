@@ -239,6 +239,15 @@ def mlp_weight_grad_all(packed, act, grads, n_points, shapes):
     return out
 
 
+def mlp_weight_grad_all_into(packed, act, grads, n_points, views):
+    """The same launch accumulating into caller-owned (dW, db) tensors (dense fp32 with the nn.Linear shapes, e.g. the
+    `.grad` views of a parallel.FlatGradBucket, already zeroed for this step)."""
+    wp = (c_void_p * len(views))(*[w.data_ptr() for w, _ in views])
+    bp = (c_void_p * len(views))(*[b.data_ptr() for _, b in views])
+    check(lib().dn_mlp_weight_grad_all(ctypes.byref(packed.desc), packed.precision, ptr(act), ptr(grads), n_points, wp, bp,
+                                       stream()), "dn_mlp_weight_grad_all")
+
+
 def run_network_pts(packed, pts, viewdirs, samples_per_ray):
     pts = f32c(pts).reshape(-1, 3)
     n_pts = pts.shape[0]

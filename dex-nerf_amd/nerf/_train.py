@@ -20,6 +20,13 @@ def needs_grad(model, *tensors):
     return any(t is not None and t.requires_grad for t in tensors) or any(p.requires_grad for p in model.parameters())
 
 
+def inputs_need_grad(*tensors):
+    """True when a gradient is wanted w.r.t. points / rays / depths / view directions (pose or ray optimisation).  The fused
+    training kernels differentiate w.r.t. the PARAMETERS only (the reference's own loop never asks for more:
+    train_dexnerf_rgb.py:246-278), so such calls take the nn.Linear autograd path instead of silently getting no gradient."""
+    return torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors)
+
+
 def train_fused_ok(model):
     return model.fused_ok() and model.num_encoding_fn_xyz == 10 and _ops._precision != _hip.PREC_F16
 
@@ -49,6 +56,9 @@ class FusedNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, pts, viewdirs, samples_per_ray, log_xyz, log_dir, *params):
         """`pts` (P,3) + `viewdirs` (N,3), or - when `samples_per_ray` is None - packed ray rows (N,11) + depths (N,S)."""
+        if inputs_need_grad(pts, viewdirs):
+            raise RuntimeError("FusedNetFn differentiates w.r.t. the model parameters only; points / rays / view directions that "
+                               "require grad must go through the nn.Linear composition (run_network does that by itself)")
         pk = model.packed(log_xyz, log_dir)
         mods = model.linear_modules()
         key = model.param_key()
@@ -62,6 +72,9 @@ class FusedNetFn(torch.autograd.Function):
         ctx.model, ctx.pk = model, pk
         ctx.n_points = out.shape[0]
         ctx.save_for_backward(act, masks)
+        ctx.sink = getattr(model, "_grad_sink", None)
+        if ctx.sink is not None:
+            ctx.sink.forward_issued()
         return out
 
     @staticmethod
@@ -91,6 +104,13 @@ class FusedNetFn(torch.autograd.Function):
         if pk.precision == _hip.PREC_BF16 or os.environ.get("DEXNERF_FP32_DW", "kernel") != "gemm":
             # every layer's weight/bias gradient straight from the native buffers, one launch (MFMA kernel, fp32 atomics)
             mods = model.linear_modules()
+            views = ctx.sink.views(model) if ctx.sink is not None else None
+            if views is not None:
+                # the parameters' `.grad` are views of a FlatGradBucket: accumulate straight into them (nothing goes back
+                # through autograd's accumulation), then let the bucket start this network's all-reduce
+                _ops.mlp_weight_grad_all_into(pk, act, grads, n, views)
+                ctx.sink.backward_done()
+                return (None,) * (6 + 2 * len(mods))
             res = _ops.mlp_weight_grad_all(pk, act, grads, n, [tuple(m.weight.shape) for m in mods])
             flat = []
             for d_w, d_b in res:
@@ -128,10 +148,37 @@ def mlp_encoded(model, x):
     return _ops.mlp_forward_encoded(model.packed(), x)
 
 
+def _torch_encoding(x, num_fns, log_sampling):
+    """positional_encoding (reference nerf/nerf_helpers.py:115-159) as differentiable torch ops on the device."""
+    if log_sampling:
+        freqs = 2.0 ** torch.linspace(0.0, num_fns - 1, num_fns, dtype=x.dtype, device=x.device)
+    else:
+        freqs = torch.linspace(2.0 ** 0.0, 2.0 ** (num_fns - 1), num_fns, dtype=x.dtype, device=x.device)
+    parts = [x]
+    for f in freqs:
+        parts += [torch.sin(x * f), torch.cos(x * f)]
+    return torch.cat(parts, dim=-1)
+
+
+def _modules_on_points(model, pts, viewdirs, log_xyz, log_dir):
+    """(N,S,3) points + (N,3) view directions through torch encodings + the nn.Linear composition: (N*S, 4), differentiable
+    w.r.t. everything."""
+    n, s = pts.shape[0], pts.shape[1]
+    emb = _torch_encoding(pts.reshape(-1, 3), model.num_encoding_fn_xyz, log_xyz)
+    if model.use_viewdirs:
+        vd = viewdirs.reshape(n, 1, 3).expand(n, s, 3).reshape(-1, 3)
+        emb = torch.cat((emb, _torch_encoding(vd, model.num_encoding_fn_dir, log_dir)), dim=-1)
+    return model._forward_modules(emb)
+
+
 def run_network_fused_rays(model, rays, z_vals, log_xyz=True, log_dir=True):
     """run_network on packed ray rows (N, 8|11) + depths (N, S): the sample points ro + rd * z are formed inside the
     kernel (reference train_utils.py:136,177 materialise them).  Returns (N, S, 4)."""
     n, s = z_vals.shape
+    if inputs_need_grad(rays, z_vals):
+        ro, rd = rays[..., :3], rays[..., 3:6]
+        pts = ro[..., None, :] + rd[..., None, :] * z_vals[..., :, None]
+        return _modules_on_points(model, pts, rays[..., -3:] if model.use_viewdirs else None, log_xyz, log_dir).reshape(n, s, 4)
     if needs_grad(model) and train_fused_ok(model):
         params = []
         for m in model.linear_modules():
@@ -141,7 +188,10 @@ def run_network_fused_rays(model, rays, z_vals, log_xyz=True, log_dir=True):
 
 
 def run_network_fused(model, pts, viewdirs, samples_per_ray, log_xyz=True, log_dir=True):
-    """run_network on raw points: positional encoding + MLP in one kernel; differentiable w.r.t. the parameters."""
+    """run_network on raw points: positional encoding + MLP in one kernel; differentiable w.r.t. the parameters.  Inputs
+    that require grad (pose / ray optimisation) take the differentiable torch composition instead."""
+    if inputs_need_grad(pts, viewdirs):
+        return _modules_on_points(model, pts.reshape(-1, samples_per_ray, 3), viewdirs, log_xyz, log_dir)
     if needs_grad(model) and train_fused_ok(model):
         params = []
         for m in model.linear_modules():

@@ -50,46 +50,115 @@ def render_sharded(render_fn, ray_origins, ray_directions):
 
 
 class FlatGradBucket:
-    """The per-step gradient exchange of the coarse+fine nets as ONE all-reduce of one contiguous buffer
-    (2 x 595,844 fp32 = 4.77 MB for D8/W256: latency-bound, one flat message is the right shape for xGMI's
-    point-to-point links).
+    """The gradients of the coarse + fine nets as slices of ONE contiguous fp32 buffer (2 x 595,844 floats = 4.77 MB for
+    D8/W256), exchanged with one all-reduce per network per step.
 
-    `zero()` drops the gradients instead of zero-filling preassigned views: autograd then ASSIGNS what the backward
-    returns (the fused training path hands back views of one buffer per network) rather than accumulating into
-    existing tensors - that accumulation was 48 four-microsecond kernels per step.  `all_reduce_mean()` gathers the
-    gradients into `flat` with one concatenation, reduces, and re-points every `.grad` at its slice; with a single rank
-    it does nothing at all."""
+    * Every `.grad` is a permanent view of `flat` (parameter order, one contiguous segment per module).  The fused training
+      path (`_train.FusedNetFn`) finds the module's segment through `module._grad_sink` and has the weight-gradient kernel
+      accumulate straight into it - no per-step allocation, no concatenation, no autograd accumulation kernels; any other
+      autograd path accumulates into the same views in place.  `zero()` is one memset of the buffer.
+    * Overlap (world > 1): a segment's all-reduce is launched asynchronously the moment its last backward has been enqueued
+      (`segment_ready`, called from FusedNetFn.backward; torch.distributed's RCCL stream waits on the compute stream by
+      itself).  Autograd reaches the fine net first, so the fine segment (2.4 MB) crosses xGMI while the coarse net's
+      backward runs; `all_reduce_mean()` then waits for what is in flight, reduces whatever was not launched (a
+      configuration outside the fused kernels) and divides by the world size.  Two ~2.4 MB messages instead of one 4.8 MB
+      one: both are latency-bound on xGMI's point-to-point links, and the first is hidden.
+    * With one rank nothing is exchanged at all."""
 
-    def __init__(self, modules):
-        self.params = [p for m in modules if m is not None for p in m.parameters() if p.requires_grad]
-        self.flat = None
+    def __init__(self, modules, overlap=True):
+        self.modules = [m for m in modules if m is not None]
+        self.params = [p for m in self.modules for p in m.parameters() if p.requires_grad]
+        self.overlap = bool(overlap)
+        dev = self.params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        self.segments, self._views, off = [], [], 0
+        for idx, m in enumerate(self.modules):
+            lo = off
+            for p in m.parameters():
+                if p.requires_grad:
+                    self._views.append(self.flat[off: off + p.numel()].view_as(p))
+                    off += p.numel()
+            self.segments.append((lo, off))
+            m._grad_sink = _GradSink(self, idx)
+        self._pending = [0] * len(self.modules)   # fused forwards of the segment's module whose backward has not run yet
+        self._works = {}
+        self._attach()
+
+    def _attach(self):
+        for p, v in zip(self.params, self._views):
+            if p.grad is not v:
+                p.grad = v
 
     def zero(self):
-        for p in self.params:
-            p.grad = None
+        """Start of a step: one memset; re-point any `.grad` something else dropped or replaced."""
+        self._attach()
+        self.flat.zero_()
+        self._pending = [0] * len(self.modules)
+        self._works = {}
 
-    def gather(self):
-        """Concatenate the current gradients into `flat` (parameter order) and make every `.grad` a view of it."""
-        self.flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off: off + p.numel()].view_as(p)
-            off += p.numel()
-        return self.flat
+    def segment(self, idx):
+        lo, hi = self.segments[idx]
+        return self.flat[lo:hi]
 
-    def all_reduce_mean(self, async_op=False):
+    def segment_ready(self, idx):
+        """All gradient kernels of module `idx` are enqueued: start its exchange (no-op with one rank / overlap off)."""
+        rank, world = world_info()
+        if world == 1 or not self.overlap or idx in self._works:
+            return
+        self._works[idx] = dist.all_reduce(self.segment(idx), op=dist.ReduceOp.SUM, async_op=True)
+
+    def all_reduce_mean(self):
+        """Finish the step's exchange: afterwards every `.grad` holds the mean over the ranks."""
         rank, world = world_info()
         if world == 1:
-            return None
-        flat = self.gather()
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
-        if not async_op:
-            flat.div_(world)
-        return work
+            return
+        if not self._works:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)          # nothing was launched early: one flat message
+        else:
+            for idx in range(len(self.modules)):
+                work = self._works.get(idx)
+                if work is None:
+                    dist.all_reduce(self.segment(idx), op=dist.ReduceOp.SUM)
+                else:
+                    work.wait()
+        self._works = {}
+        self.flat.div_(world)
+
+
+class _GradSink:
+    """Handle a module carries to its segment of a FlatGradBucket (see FusedNetFn)."""
+
+    def __init__(self, bucket, idx):
+        self.bucket, self.idx = bucket, idx
+
+    def views(self, module):
+        """[(dW, db)] views of the bucket in module.linear_modules() order, or None when a `.grad` is not (any more) the
+        bucket's view - the caller then returns gradients to autograd the ordinary way."""
+        out = []
+        for lin in module.linear_modules():
+            w, b = lin.weight.grad, lin.bias.grad
+            if w is None or b is None or w.untyped_storage().data_ptr() != self.bucket.flat.untyped_storage().data_ptr() \
+                    or b.untyped_storage().data_ptr() != self.bucket.flat.untyped_storage().data_ptr():
+                return None
+            out.append((w, b))
+        return out
+
+    def forward_issued(self):
+        self.bucket._pending[self.idx] += 1
+
+    def backward_done(self):
+        self.bucket._pending[self.idx] -= 1
+        if self.bucket._pending[self.idx] <= 0:
+            self.bucket.segment_ready(self.idx)
 
 
 def broadcast_parameters(modules, src=0):
-    """Make every rank start from rank `src`'s weights."""
+    """Make every rank start from rank `src`'s weights.
+
+    The broadcast writes through `t.data`, which does not bump the tensors' versions: the packed-weight caches
+    (FlexibleNeRFModel.param_key) are told explicitly, so a model that rendered or trained before the broadcast does not keep
+    serving its old MFMA weight stream on the non-source ranks.  The same call - `nerf.models.mark_parameters_updated()` - is
+    what any other out-of-band parameter write (`p.data.copy_`, an EMA swap, a manual sync) must be followed by."""
     rank, world = world_info()
     if world == 1:
         return
@@ -98,3 +167,5 @@ def broadcast_parameters(modules, src=0):
             continue
         for t in list(m.parameters()) + list(m.buffers()):
             dist.broadcast(t.data, src)
+    from .models import mark_parameters_updated
+    mark_parameters_updated()

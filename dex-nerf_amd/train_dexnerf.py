@@ -218,6 +218,7 @@ def main(argv=None):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     iteration()
+                graph.replay()                         # a capture only records: this iteration's step runs here
                 nerf.models.mark_parameters_updated()
             except Exception as exc:  # noqa: BLE001
                 graph, use_graph = None, False
@@ -256,8 +257,11 @@ def main(argv=None):
         m_best, err = dex_sweep(out, depths[held_out], thres, data["mask_hi"])
         result["dex_best_threshold"], result["dex_abs_err_mm"] = int(m_best), err["depth_abs_err"]
         if args.save:
+            opt_state = opt.state_dict()
+            for group in opt_state["param_groups"]:   # the reference stores a Python float (train_dexnerf_rgb.py:443-456), not the
+                group["lr"] = float(group["lr"])     # device scalar the captured graph reads the schedule from
             torch.save({"iter": args.iters, "model_coarse_state_dict": student[0].state_dict(),
-                        "model_fine_state_dict": student[1].state_dict(), "optimizer_state_dict": opt.state_dict(),
+                        "model_fine_state_dict": student[1].state_dict(), "optimizer_state_dict": opt_state,
                         "loss": loss_val, "psnr": psnr}, args.save)
         if not args.quiet:
             print(f"[done] {args.iters - start} iters in {elapsed:.1f} s = {result['rays_per_s']:.0f} rays/s; "

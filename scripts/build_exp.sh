@@ -7,7 +7,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 C=$REPO/dex-nerf_amd/csrc
 NAME=$1; FLAGS=$2; shift 2 || true
 FILES=${@:-mlp_fused.hip mlp_train.hip}
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function"
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function -DDN_ABLATION_BUILD"
 make -C $C -j8 >/dev/null
 mkdir -p $REPO/exp_libs $C/build/exp_$NAME
 OBJS=""

@@ -1,18 +1,21 @@
 #!/bin/bash
-# Developer tool (GPU box): HBM traffic and L2 hit rate of the bf16 fine-net launch (separate --pmc passes, as the microarch
-# guide prescribes).  Output: gpurun_out/pmc_fine_net.txt
+# Developer tool (GPU box): PMC passes on the bf16 fine-net launch (scripts/quick_time.py bf16 160000 = 160,000 rays x 192
+# points through the kernel bench.py times).  ONE counter group per rocprofv3 run: FETCH_SIZE costs 3 of the 4 TCC slots and
+# WRITE_SIZE 2 (MI355X_MICROARCH.md, rocprofv3 PMC slots) - asking for both in one pass aborts the profiler with
+# "error code 38: Request exceeds the capabilities of the hardware to collect" (that was round 1's "pass does not complete").
+#   usage: scripts/pmc_fine_net.sh [tag] [ENV=VAL ...]      output: gpurun_out/pmc_<tag>.json (+ per-pass logs / csv)
+tag=${1:-fine_net}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE --output-format csv -d gpurun_out/pmc_fn_hbm -- python3 scripts/quick_time.py bf16 160000 > gpurun_out/pmc_fn_hbm.log 2>&1 || echo "FETCH/WRITE pass failed"
-timeout -k 10 150 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc_fn_l2 -- python3 scripts/quick_time.py bf16 160000 > gpurun_out/pmc_fn_l2.log 2>&1 || echo "TCC pass failed"
-python3 - <<'PY'
-import csv, glob
-for st in ("hbm", "l2"):
-    fs = glob.glob("gpurun_out/pmc_fn_%s/*/*counter_collection.csv" % st)
-    if not fs: print(st, "no output"); continue
-    last = {}
-    for r in csv.DictReader(open(fs[0])):
-        if "mlp_forward" in r["Kernel_Name"]:
-            last[r["Counter_Name"]] = float(r["Counter_Value"]); name = r["Kernel_Name"]
-    print(st, name[:60], last)
-PY
+for kv in "$@"; do export "$kv"; done
+pass() {  # name, counters...
+  name=$1; shift
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}_$name -- python3 scripts/quick_time.py bf16 160000 > gpurun_out/pmc_${tag}_$name.log 2>&1 || echo "pass $name failed (see gpurun_out/pmc_${tag}_$name.log)"
+}
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass l2 TCC_HIT_sum TCC_MISS_sum
+pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+pass sqA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC
+pass sqB SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_MOPS_BF16
+python3 scripts/pmc_collect.py $tag

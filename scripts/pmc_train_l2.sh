@@ -5,13 +5,15 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for tag in nt plain; do
   if [ $tag = plain ]; then export DEXNERF_HIP_LIB=exp_libs/libPLAINST.so; else unset DEXNERF_HIP_LIB; fi
   rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc_train_${tag}_l2 -- python3 scripts/train_kernels_time.py > gpurun_out/pmc_train_${tag}_l2.log 2>&1
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE --output-format csv -d gpurun_out/pmc_train_${tag}_hbm -- python3 scripts/train_kernels_time.py > gpurun_out/pmc_train_${tag}_hbm.log 2>&1
+  # FETCH_SIZE (3 TCC slots) and WRITE_SIZE (2) do not fit one pass (4 slots): one run each
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_train_${tag}_fetch -- python3 scripts/train_kernels_time.py > gpurun_out/pmc_train_${tag}_fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_train_${tag}_write -- python3 scripts/train_kernels_time.py > gpurun_out/pmc_train_${tag}_write.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections, json
 out = {}
 for tag in ("nt", "plain"):
-    for st in ("l2", "hbm"):
+    for st in ("l2", "fetch", "write"):
         f = glob.glob(f"gpurun_out/pmc_train_{tag}_{st}/*/*counter_collection.csv")[0]
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):

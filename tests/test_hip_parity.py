@@ -1061,3 +1061,151 @@ def test_48_point_geometry_against_32_point_and_fp32(dev, monkeypatch, prec16):
         assert torch.equal(a, b)
     finally:
         nerf.set_precision("fp32")
+
+
+# ---- the kernel / configurations the bench line times, gated against the reference-recorded golden and the oracle ----
+def dex_agreement(dex, dex_ref, tol_scale=TOL):
+    """Dex-depth agreement between two (K, N) stacks: fraction of (threshold, ray) entries within tol_scale * max|ref|,
+    and the worst absolute miss in metres (a flipped first-crossing moves the readout to another sample's depth)."""
+    dex, dex_ref = np.asarray(dex, np.float64), np.asarray(dex_ref, np.float64)
+    miss = np.abs(dex - dex_ref)
+    return float((miss <= tol_scale * np.abs(dex_ref).max()).mean()), float(miss.max())
+
+
+def psnr_db(a, b, peak=1.0):
+    mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
+    return float(10.0 * np.log10(peak * peak / max(mse, 1e-14)))
+
+
+@pytest.mark.parametrize("precision,rgb_floor,depth_floor,dex_floor", [("bf16", 40.0, 40.0, 0.90), ("fp16", 55.0, 55.0, 0.97)])
+def test_headline_kernel_16bit_against_reference_golden(golden, dev, precision, rgb_floor, depth_floor, dex_floor):
+    """What bench.py times - D8/W256, 64+128, the 48-points-per-wave 16-bit kernel - end to end on the rays of the
+    reference-recorded golden `render_d8w256_val` (192 rays; fp32 reference outputs): rgb PSNR, depth PSNR (peak = far - near
+    = 4 m) and Dex-depth agreement (reference nerf/volume_rendering_utils.py:51-58: the readout is a thresholded first
+    crossing, so one flipped sample moves it by a whole sample spacing or more).  Stage-wise as well: the 16-bit fine
+    network on the golden fine points, Dex readout on ITS sigma against the readout on the golden sigma at identical depths -
+    isolates the network's arithmetic from the resampling it feeds."""
+    import nerf
+    from nerf import _ops
+    name = "render_d8w256_val"
+    g = golden(name)
+    mkw, wfn, rkw = CASES[name]
+    mc, mf = make_models(mkw, *wfn(), dev)
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    thres = list(M_THRES)
+    nerf.set_precision(precision)
+    try:
+        with torch.no_grad():
+            out = nerf.run_one_iter_of_nerf(1, len(g["ro"]), 1.0, mc, mf, G(g["ro"], dev)[None], G(g["rd"], dev)[None],
+                                            make_cfg(rkw), mode="validation", encode_position_fn=ex,
+                                            encode_direction_fn=ed, m_thres_cand=thres)
+            rd = torch.from_numpy(g["rd"])
+            vd = (rd / rd.norm(p=2, dim=-1).unsqueeze(-1)).to(dev)
+            rays = torch.cat([G(g["ro"], dev), G(g["rd"], dev), torch.zeros(len(rd), 2, device=dev), vd], -1)
+            rf16 = nerf.run_network(mf, G(g["pts_fine"], dev), rays, 4096, ex, ed)
+    finally:
+        nerf.set_precision("fp32")
+    rgb_psnr = psnr_db(C(out[3]).reshape(-1, 3), g["out_rgb_fine"])
+    depth_psnr = psnr_db(C(out[4]).reshape(-1), g["out_depth_fine"], peak=4.0)
+    dex = np.stack([C(o).reshape(-1) for o in out[6:]])
+    frac, worst = dex_agreement(dex, g["out_dex_fine"])
+    # stage-wise: same depths, only sigma differs
+    z = G(g["z_fine"], dev)
+    rdv = G(g["rd"], dev)
+    with torch.no_grad():
+        dex16 = _ops.volume_render_fwd(rf16, z, rdv, None, 0.0, False, thres, want_weights=False)[5]
+        dex32 = _ops.volume_render_fwd(G(g["rf_fine"], dev), z, rdv, None, 0.0, False, thres, want_weights=False)[5]
+    sfrac, sworst = dex_agreement(C(dex16), C(dex32))
+    sig_err = rel_err(C(rf16)[..., 3], g["rf_fine"][..., 3])
+    print(f"{precision} D8/W256 64+128 vs reference golden: rgb {rgb_psnr:.1f} dB, depth {depth_psnr:.1f} dB, Dex agreement "
+          f"{frac:.4f} (worst miss {worst:.3f} m); fixed-depth Dex agreement {sfrac:.4f} (worst {sworst:.3f} m), sigma rel err {sig_err:.2e}")
+    assert rgb_psnr > rgb_floor and depth_psnr > depth_floor
+    assert frac > dex_floor and sfrac > dex_floor
+    assert np.array_equal(C(dex32), g["vf_dex"])  # the readout itself is exact on the golden sigma
+
+
+@pytest.mark.parametrize("nc,nf,tag", [(64, 192, "config 4 sampling"), (128, 256, "config 5 sampling")])
+def test_config4_and_config5_sampling_on_d8w256_fp32(dev, nc, nf, tag):
+    """BASELINE.json configs[3] (64+192) and configs[4] (128+256, fp32) sample counts on the D8/W256 nets those configs name,
+    256 rays of a scene view, exact-fp32 mode against the CPU oracle at 1e-4."""
+    import nerf
+    from nerf import synthetic as syn
+    from oracle import nerf_oracle as oc
+    kw = CASES["render_d8w256_val"][0]
+    sd_c, sd_f = CASES["render_d8w256_val"][1]()
+    mc, mf = make_models(kw, sd_c, sd_f, dev)
+    h = w = 800
+    e_mat, k_mat = torch.from_numpy(syn.scene_pose(5)), torch.from_numpy(syn.intrinsic(h, w))
+    ro, rd = nerf.get_ray_bundle(h, w, float(k_mat[0, 0]), e_mat.to(dev), k_mat.to(dev))
+    sel = torch.from_numpy(syn.select_rays(h, w, 256, seed=nc + nf)).to(dev)
+    ro, rd = ro.reshape(-1, 3)[sel].contiguous(), rd.reshape(-1, 3)[sel].contiguous()
+    rkw = dict(num_coarse=nc, num_fine=nf, near=2.0, far=6.0)
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    with torch.no_grad():
+        out = nerf.run_one_iter_of_nerf(h, w, 1.0, mc, mf, ro, rd, make_cfg(rkw, 4096), mode="train", encode_position_fn=ex,
+                                        encode_direction_fn=ed, m_thres_cand=list(M_THRES))
+    cfg_o = oc.RenderCfg(chunksize=4096, m_thres=M_THRES, **rkw)
+    mcfg = oc.ModelCfg(**kw)
+    with torch.no_grad():
+        ref = oc.run_one_iter(ro.cpu(), rd.cpu(), oc.to_torch_sd(sd_c), oc.to_torch_sd(sd_f), mcfg, mcfg, cfg_o)
+    for i in range(6):
+        assert rel_err(C(out[i]), ref[i].numpy()) < TOL, (tag, i)
+    frac, worst = dex_agreement(np.stack([C(o) for o in out[6:]]), np.stack([o.numpy() for o in ref[6:]]))
+    print(f"{tag}: Dex agreement {frac:.4f}, worst miss {worst:.3f} m")
+    assert frac > 0.995, (tag, frac)
+
+
+def test_config4_full_size_render_properties_bf16(dev):
+    """BASELINE.json configs[3] at full size on one GPU: 800x800 rays, 64+192 samples, D8/W256, bf16 (the 48-point kernel) -
+    too large for the oracle, so size-independent properties: determinism, chunk invariance (one 640,000-ray chunk vs
+    ragged 100,003-ray chunks: bit-identical), ascending merged depths, acc == sum(weights), acc in [0, 1], finite maps,
+    Dex depths inside [near, far]; and a 512-ray subset against the fp32 oracle on PSNR."""
+    import nerf
+    from nerf import _ops, synthetic as syn
+    from oracle import nerf_oracle as oc
+    kw = CASES["render_d8w256_val"][0]
+    sd_c, sd_f = CASES["render_d8w256_val"][1]()
+    mc, mf = make_models(kw, sd_c, sd_f, dev)
+    h = w = 800
+    e_mat, k_mat = torch.from_numpy(syn.scene_pose(2)), torch.from_numpy(syn.intrinsic(h, w))
+    ro, rd = nerf.get_ray_bundle(h, w, float(k_mat[0, 0]), e_mat.to(dev), k_mat.to(dev))
+    rkw = dict(num_coarse=64, num_fine=192, near=2.0, far=6.0)
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    nerf.set_precision("bf16")
+    try:
+        def run(chunk):
+            with torch.no_grad():
+                return nerf.run_one_iter_of_nerf(h, w, 1.0, mc, mf, ro, rd, make_cfg(rkw, chunk), mode="validation",
+                                                 encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=list(M_THRES))
+        a = run(h * w)
+        b = run(h * w)
+        c = run(100003)
+        for x, y, z_ in zip(a, b, c):
+            assert x.shape[:2] == (h, w)
+            assert torch.equal(x, y)      # deterministic
+            assert torch.equal(x, z_)     # chunking never changes a bit
+        for t in a[:6]:
+            assert bool(torch.isfinite(t).all())
+        acc = a[5]
+        assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
+        dex = torch.stack(list(a[6:]))
+        assert float(dex.min()) >= 2.0 - 1e-4 and float(dex.max()) <= 6.0 + 1e-4
+        # stage properties on a 65,536-ray block of the same image
+        rays = oc.pack_rays(ro.reshape(-1, 3)[:65536].cpu(), rd.reshape(-1, 3)[:65536].cpu(), oc.RenderCfg(chunksize=4096, m_thres=M_THRES, **rkw)).to(dev)
+        z_c = _ops.coarse_depths(rays, 64, False, None)
+        rf = _ops.run_network_rays(mc.packed(), rays, z_c)
+        _, _, acc_c, wts, _, _ = _ops.volume_render_fwd(rf, z_c, rays[:, 3:6], None, 0.0, False, [])
+        assert rel_err(C(wts.sum(-1)), C(acc_c)) < 1e-5
+        z_f = _ops.fine_depths(z_c, wts, 192, None)
+        assert z_f.shape == (65536, 256) and bool((z_f[:, 1:] >= z_f[:, :-1]).all())
+    finally:
+        nerf.set_precision("fp32")
+    sel = torch.from_numpy(syn.select_rays(h, w, 512, seed=4)).to(dev)
+    cfg_o = oc.RenderCfg(chunksize=4096, m_thres=M_THRES, **rkw)
+    mcfg = oc.ModelCfg(**kw)
+    with torch.no_grad():
+        ref = oc.run_one_iter(ro.reshape(-1, 3)[sel].cpu(), rd.reshape(-1, 3)[sel].cpu(), oc.to_torch_sd(sd_c), oc.to_torch_sd(sd_f), mcfg, mcfg, cfg_o)
+    psnr = psnr_db(C(a[3].reshape(-1, 3)[sel]), ref[3].numpy())
+    frac, worst = dex_agreement(np.stack([C(o.reshape(-1)[sel]) for o in a[6:]]), np.stack([o.numpy() for o in ref[6:]]))
+    print(f"800x800 64+192 bf16: rgb PSNR {psnr:.1f} dB vs the fp32 oracle on 512 rays; Dex agreement {frac:.4f}, worst miss {worst:.3f} m")
+    assert psnr > 38.0

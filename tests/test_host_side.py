@@ -199,3 +199,38 @@ def test_committed_bench_line_follows_the_contract():
     # value = rays of all ranks / time: consistent with ms_per_step
     rays = line["config"]["rays_per_step_per_gpu"] * line["n_gpus"]
     assert abs(line["value"] - rays / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+
+
+def test_run_reference_launcher_resolves_the_builds_package(tmp_path):
+    """The drop-in launcher (dex-nerf_amd/run_reference.py): a script that sits next to a decoy `nerf/` directory - the
+    situation of every reference script (train_dexnerf_rgb.py:15-19 beside nerf-pytorch/nerf/) - must import THIS build's
+    package, keep its sibling modules importable and run with its own directory as the working directory.  The plain
+    `PYTHONPATH=... python script.py` launch of the same script resolves to the decoy (sys.path[0] = script directory):
+    that is the pitfall the launcher exists for."""
+    import subprocess
+    import sys
+    scripts = tmp_path / "nerf-pytorch"
+    (scripts / "nerf").mkdir(parents=True)
+    (scripts / "nerf" / "__init__.py").write_text("WHO = 'decoy'\n")
+    (scripts / "sibling_helper.py").write_text("VALUE = 41\n")
+    (scripts / "train_dummy.py").write_text(
+        "import os, sys\nimport nerf\nimport sibling_helper\n"
+        "from nerf import CfgNode, get_embedding_function, get_ray_bundle, models, run_one_iter_of_nerf\n"
+        "print('NERF_FILE=' + os.path.abspath(nerf.__file__))\nprint('CWD=' + os.getcwd())\n"
+        "print('ARGV=' + ' '.join(sys.argv[1:]))\nprint('SIB=%d' % (sibling_helper.VALUE + 1))\n"
+        "print('MAIN=' + __name__)\n")
+    pkg = os.path.join(REPO, "dex-nerf_amd")
+    env = dict(os.environ)
+    env.pop("PYTHONPATH", None)
+    r = subprocess.run([sys.executable, os.path.join(pkg, "run_reference.py"), str(scripts / "train_dummy.py"), "--config", "x.yml"],
+                       capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = dict(line.split("=", 1) for line in r.stdout.strip().splitlines() if "=" in line)
+    assert out["NERF_FILE"] == os.path.join(pkg, "nerf", "__init__.py")
+    assert os.path.realpath(out["CWD"]) == os.path.realpath(str(scripts))
+    assert out["ARGV"] == "--config x.yml" and out["SIB"] == "42" and out["MAIN"] == "__main__"
+    # the PYTHONPATH recipe does NOT do this: the script directory wins
+    env["PYTHONPATH"] = pkg
+    (scripts / "which.py").write_text("import nerf\nprint(getattr(nerf, 'WHO', 'build'))\n")
+    r2 = subprocess.run([sys.executable, str(scripts / "which.py")], capture_output=True, text=True, env=env, timeout=300)
+    assert r2.stdout.strip() == "decoy"

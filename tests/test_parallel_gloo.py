@@ -50,6 +50,7 @@ def _case_render_sharded(rank, world, tmp):
 
 
 def _case_flat_bucket(rank, world, tmp):
+    """Eager path (no segment launched early): one flat all-reduce; every .grad stays a view of the bucket."""
     from nerf import models, parallel
     torch.manual_seed(100 + rank)  # different init per rank on purpose
     coarse = models.FlexibleNeRFModel(num_layers=3, hidden_size=32)
@@ -57,19 +58,22 @@ def _case_flat_bucket(rank, world, tmp):
     parallel.broadcast_parameters([coarse, fine], src=0)
     bucket = parallel.FlatGradBucket([coarse, fine])
     n_params = sum(p.numel() for m in (coarse, fine) for p in m.parameters())
+    assert bucket.flat.numel() == n_params and bucket.segments == [(0, n_params // 2), (n_params // 2, n_params)]
     opt = torch.optim.Adam(bucket.params, lr=1e-2)
     torch.manual_seed(7 + rank)  # each rank: its own rays
+    lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + 4 * n_params
     for step in range(3):
         x = torch.randn(16, coarse.dim_xyz + coarse.dim_dir)
+        if step == 1:
+            opt.zero_grad(set_to_none=True)     # something dropped the grads: zero() re-points them at the bucket
         bucket.zero()
-        assert all(p.grad is None for p in bucket.params)      # autograd will assign, not accumulate
+        assert all(lo <= p.grad.data_ptr() < hi for p in bucket.params) and float(bucket.flat.abs().max()) == 0.0
         loss = coarse(x).pow(2).mean() + fine(x).pow(2).mean()
-        loss.backward()
-        local = torch.cat([p.grad.reshape(-1) for p in bucket.params]).clone()
+        loss.backward()                          # autograd accumulates in place into the bucket's views
+        assert all(lo <= p.grad.data_ptr() < hi for p in bucket.params)
+        local = bucket.flat.clone()
+        assert torch.equal(local, torch.cat([p.grad.reshape(-1) for p in bucket.params]))
         bucket.all_reduce_mean()
-        assert bucket.flat.numel() == n_params
-        lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + 4 * n_params
-        assert all(lo <= p.grad.data_ptr() < hi for p in bucket.params)   # every grad is now a view of the reduced buffer
         gathered = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(gathered, local)
         assert torch.allclose(bucket.flat, sum(gathered) / world, atol=1e-7)
@@ -80,12 +84,85 @@ def _case_flat_bucket(rank, world, tmp):
     assert torch.equal(gathered[0], gathered[1])  # replicas stayed bit-identical
 
 
+def _case_flat_bucket_overlapped(rank, world, tmp):
+    """The overlapped path: each network's segment is all-reduced asynchronously as soon as its backward is complete
+    (what FusedNetFn.backward triggers through module._grad_sink on the GPU), the other network's backward runs meanwhile,
+    all_reduce_mean() waits, reduces what was not launched and averages.  Replicas stay bit-identical, and the result equals
+    the eager single-message path bit for bit (same SUM over the same two ranks, same division)."""
+    from nerf import models, parallel
+    torch.manual_seed(5)
+    nets = [models.FlexibleNeRFModel(num_layers=3, hidden_size=32) for _ in range(2)]
+    ref_nets = [models.FlexibleNeRFModel(num_layers=3, hidden_size=32) for _ in range(2)]
+    for a, b in zip(nets, ref_nets):
+        b.load_state_dict(a.state_dict())
+    bucket = parallel.FlatGradBucket(nets, overlap=True)
+    ref = parallel.FlatGradBucket(ref_nets, overlap=False)
+    opt = torch.optim.Adam(bucket.params, lr=1e-2)
+    opt_ref = torch.optim.Adam(ref.params, lr=1e-2)
+    torch.manual_seed(70 + rank)
+    for step in range(4):
+        x = torch.randn(16, nets[0].dim_xyz + nets[0].dim_dir)
+        bucket.zero(); ref.zero()
+        sinks = [m._grad_sink for m in nets]
+        # fine first (autograd's order on the real path), its exchange in flight during the coarse backward
+        sinks[1].forward_issued(); sinks[0].forward_issued()
+        if step == 2:
+            sinks[1].forward_issued()             # two chunks through the fine net: the exchange starts after the LAST backward
+        nets[1](x).pow(2).mean().backward()
+        sinks[1].backward_done()
+        if step == 2:
+            assert 1 not in bucket._works
+            nets[1](x * 0.5).pow(2).mean().backward()
+            sinks[1].backward_done()
+        assert 1 in bucket._works and 0 not in bucket._works
+        nets[0](x).pow(2).mean().backward()
+        if step != 3:
+            sinks[0].backward_done()              # step 3: the coarse segment is never launched early -> reduced in all_reduce_mean
+        bucket.all_reduce_mean()
+        (ref_nets[1](x).pow(2).mean() + ref_nets[0](x).pow(2).mean()).backward()
+        if step == 2:
+            ref_nets[1](x * 0.5).pow(2).mean().backward()
+        ref.all_reduce_mean()
+        assert torch.equal(bucket.flat, ref.flat), step
+        opt.step(); opt_ref.step()
+    flat_w = torch.cat([p.detach().reshape(-1) for p in bucket.params])
+    gathered = [torch.empty_like(flat_w) for _ in range(world)]
+    dist.all_gather(gathered, flat_w)
+    assert torch.equal(gathered[0], gathered[1])
+    assert torch.equal(flat_w, torch.cat([p.detach().reshape(-1) for p in ref.params]))
+
+
+def _case_broadcast_invalidates_packed_cache(rank, world, tmp):
+    """broadcast_parameters writes through .data (no version bump): the packed-weight cache key must change anyway, or a
+    model that packed before the broadcast keeps serving its old weight stream on the non-source ranks."""
+    from nerf import models, parallel
+    torch.manual_seed(300 + rank)
+    m = models.FlexibleNeRFModel(num_layers=3, hidden_size=32)
+    key_before = m.param_key()
+    versions = [p._version for p in m.parameters()]
+    parallel.broadcast_parameters([m], src=0)
+    assert [p._version for p in m.parameters()] == versions      # .data writes are invisible to the version counters
+    assert m.param_key() != key_before
+    w = m.layer1.weight.detach().clone()
+    gathered = [torch.empty_like(w) for _ in range(world)]
+    dist.all_gather(gathered, w)
+    assert torch.equal(gathered[0], gathered[1])
+
+
 def test_render_sharded_world2(tmp_path):
     _run("_case_render_sharded", tmp_path)
 
 
 def test_flat_grad_bucket_world2(tmp_path):
     _run("_case_flat_bucket", tmp_path)
+
+
+def test_flat_grad_bucket_overlapped_world2(tmp_path):
+    _run("_case_flat_bucket_overlapped", tmp_path)
+
+
+def test_broadcast_invalidates_packed_cache_world2(tmp_path):
+    _run("_case_broadcast_invalidates_packed_cache", tmp_path)
 
 
 def test_shard_bounds_cover_everything():

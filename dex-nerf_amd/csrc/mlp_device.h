@@ -119,6 +119,20 @@ struct Pipe {
   const char* rd_nxt;
   unsigned lane16;
   f32x4 af[kPrefetch];  // A-fragment FIFO: af[pos % kPrefetch] holds piece `pos` when it is consumed
+#ifdef DN_PIPE_ASM_READS
+  // Explicit LDS read pipeline (mlp_fused48.hip).  hipcc's own waitcnt insertion turns a depth-2 software pipeline of
+  // ds_read_b128 into "issue the read for piece p+2, then s_waitcnt lgkmcnt(0)": every other piece, and every tile's bias
+  // read, exposed a full LDS round trip in front of the MFMAs (r02 PMC: waves parked in s_waitcnt 39 % of their cycles).
+  // Here the reads and their COUNTED waits are opaque asm statements: a consumer waits with lgkmcnt(N), N = the number of
+  // our own reads issued after the one it needs (LDS returns in order; any compiler-issued LDS access in between only
+  // makes the wait stricter, never weaker).  The value flows read-asm -> wait-asm ("+v") -> MFMA, so the compiler cannot
+  // use a fragment before its wait; tests/test_asm_hazards.py checks in the disassembly that nothing touches a fragment
+  // register between its ds_read and its wait.
+  unsigned rda_cur;            // 32-bit LDS byte address (+ lane * 16) of the current phase slot; the next slot's is formed
+                               // where it is needed (the last kPrefetch pieces of a phase) from the scalar slot base
+  unsigned slot_cur_base;      // (scalar) LDS byte address of the slot of the NEXT phase (becomes rda_cur at phase_begin)
+  f32x4 bias_nxt;              // bias rows of the NEXT 16-row tile, read two pieces ahead of its first MFMA
+#endif
 #ifdef DN_EXP_REGSTAGE
   f32x4 stage[PER_WAVE];
   unsigned stage_dst;
@@ -220,6 +234,11 @@ struct Pipe {
     if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
 #endif
+#elif defined(DN_PIPE_ASM_READS)
+    // No LDS wait here: every read of the slot being recycled (phase p-1) was waited for by the take() in front of its
+    // MFMAs, which precede this point in program order; the reads still in flight belong to phases p and p+1.
+    static_assert(PER_WAVE == 2, "the asm-read pipeline is the 8-wave geometry");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #else
     if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -246,9 +265,14 @@ struct Pipe {
     advance_issue();
     dma_phase(pend_src, pend_dst, (WAVES == 4 || wave < 4) ? 1u : 0u);
 #endif
-    rd_cur = rd_nxt;
     slot_nxt = (slot_nxt + 1 == kRingPhases) ? 0 : slot_nxt + 1;
+#ifdef DN_PIPE_ASM_READS
+    rda_cur = slot_cur_base + lane16;
+    slot_cur_base = __builtin_amdgcn_readfirstlane(ring_addr + slot_nxt * kSlotBytes);   // now the NEXT phase's slot
+#else
+    rd_cur = rd_nxt;
     rd_nxt = ring + slot_nxt * kSlotBytes + lane16;
+#endif
   }
 
   __device__ __forceinline__ void mid_phase() {
@@ -265,19 +289,64 @@ struct Pipe {
       constexpr int pos = POS + decltype(i_c)::value;
       static_assert(pos % kPhasePieces != 0 || decltype(i_c)::value == 0, "padding never crosses a phase");
       if constexpr (pos % kPhasePieces == kPhasePieces / 2) mid_phase();
+#ifdef DN_PIPE_ASM_READS
+      // only the last kPrefetch skipped positions fetch pieces that will be consumed (the first pieces of the next pass)
+      if constexpr (decltype(i_c)::value >= N - kPrefetch) prefetch<pos>();
+#else
       prefetch<pos>();
+#endif
     });
+#ifdef DN_PIPE_ASM_READS
+    settle();
+#endif
   }
 
   // after consuming piece POS (position within the 16-piece phase), read piece POS + kPrefetch into its FIFO slot
   template <int POS>
   __device__ __forceinline__ void prefetch() {
     constexpr int q = (POS % kPhasePieces) + kPrefetch;
+#ifdef DN_PIPE_ASM_READS
+    const unsigned base = (q < kPhasePieces) ? rda_cur : slot_cur_base + lane16;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[POS % kPrefetch]) : "v"(base), "n"((q % kPhasePieces) * kPieceBytes));
+#else
     const char* base = (q < kPhasePieces) ? rd_cur : rd_nxt;
 #ifndef DN_EXP_NOREAD
     af[POS % kPrefetch] = *reinterpret_cast<const f32x4*>(base + (q % kPhasePieces) * kPieceBytes);
 #endif
+#endif
   }
+
+#ifdef DN_PIPE_ASM_READS
+  // prologue: FIFO entry E (piece E of the first phase) from the slot rda_nxt points at
+  template <int E>
+  __device__ __forceinline__ void prologue_read() {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[E]) : "v"(slot_cur_base + lane16), "n"(E * kPieceBytes));
+  }
+  // piece POS is about to be consumed: wait until at most NEWER of our younger reads are outstanding
+  template <int POS, int NEWER>
+  __device__ __forceinline__ f32x4 take() {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[POS % kPrefetch]) : "n"(NEWER));
+    return af[POS % kPrefetch];
+  }
+  // bias rows of the next tile: addr = LDS byte address of this lane group's 16 bytes of a bias tile, OFF = byte offset
+  template <int OFF>
+  __device__ __forceinline__ void bias_prefetch(unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bias_nxt) : "v"(addr), "n"(OFF));
+  }
+  template <int NEWER>
+  __device__ __forceinline__ f32x4 bias_take() {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bias_nxt) : "n"(NEWER));
+    return bias_nxt;
+  }
+  // Land everything in flight.  To the compiler a fragment is an ordinary value from its read-asm on, so wherever control
+  // flow merges (the trunk's run-time layer loop, the skip / no-skip branch, the tile loop) it may copy the FIFO registers
+  // (phi copies) - before the data has arrived, if a read were still in flight there.  Called at the end of every stage
+  // and after the padding pieces: one exposed LDS round trip per stage (12 per 1184 pieces).
+  __device__ __forceinline__ void settle() {
+    static_assert(kPrefetch == 2, "settle() names both FIFO entries");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bias_nxt));
+  }
+#endif
 };
 
 template <int BF16>

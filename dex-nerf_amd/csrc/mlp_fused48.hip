@@ -12,6 +12,9 @@
 #endif
 #define DN_PREFETCH DN_G48_PREFETCH
 #define DN_PIPE_SCALAR_STATE 1   // ring bookkeeping in SGPRs: frees the VGPRs that were spilling (0.5 % on the launch)
+#ifndef DN_G48_COMPILER_READS    // (ablation hook: the r01 pipeline with compiler-issued reads and waits)
+#define DN_PIPE_ASM_READS 1      // A-fragment / bias LDS reads and their counted waits as opaque asm (mlp_device.h Pipe)
+#endif
 #include "mlp_geo48.h"
 
 namespace dn {
@@ -24,33 +27,61 @@ __device__ __forceinline__ f32x4 mfma48(typename Prec<F>::BPiece a, typename Pre
 }
 
 // One GEMM stage: NT_OUT 16-row output tiles, KH hidden pieces + KP encoding pieces per tile, three point groups.
-template <int F, int NT_OUT, int KH, int KP, int POS0, class PipeT, class BH, class BP, class Emit>
-__device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, const char* bias_g, Emit&& emit) {
+// bias_addr: LDS byte address of this lane group's 16 bytes of the stage's bias tile 0; the bias tiles of a tile pass are
+// contiguous in stream order, so "the next tile's bias" is the next 64 bytes, except after the last stage of the pass
+// (LAST): there it is next_addr (tile 0 of layer1).  Read pipeline (DN_PIPE_ASM_READS): step k of a tile = take A(p),
+// three MFMAs, read A(p+2); the next tile's bias read goes out right after the A read of step KT-2, i.e. between A(next
+// tile, 0) and A(next tile, 1) - so the wait counts are 1 everywhere (at k = 0 that covers the bias too) and 2 at k = KT-1.
+template <int F, int NT_OUT, int KH, int KP, int POS0, bool LAST = false, class PipeT, class BH, class BP, class Emit>
+__device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, unsigned bias_addr, unsigned next_addr, Emit&& emit) {
   constexpr int PT = 3, KT = KH + KP;
+  static_assert(KT >= 2, "the bias prefetch distance assumes at least two pieces per tile");
   static_for<NT_OUT>([&](auto nt_c) {
     constexpr int nt = decltype(nt_c)::value;
-    const f32x4 b = *reinterpret_cast<const f32x4*>(bias_g + nt * 64);
     f32x4 acc[PT];
-#pragma unroll
-    for (int t = 0; t < PT; ++t) acc[t] = b;
     static_for<KT>([&](auto k_c) {
       constexpr int k = decltype(k_c)::value;
       constexpr int pos = POS0 + nt * KT + k;
       if constexpr (pos % kPhasePieces == 0) pipe.phase_begin();
       if constexpr (pos % kPhasePieces == kPhasePieces / 2) pipe.mid_phase();
+#ifdef DN_PIPE_ASM_READS
+      if constexpr (k == 0) {
+        const f32x4 b = pipe.template bias_take<1>();   // issued before A(pos + 1): one younger read may stay in flight
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[t] = b;
+      }
+      const auto a = __builtin_bit_cast(typename Prec<F>::BPiece, pipe.template take<pos, (k == KT - 1) ? 2 : 1>());
+#else
+      if constexpr (k == 0) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(pipe.ring + (bias_addr - pipe.ring_addr) + nt * 64);
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[t] = b;
+      }
       const auto a = __builtin_bit_cast(typename Prec<F>::BPiece, pipe.af[pos % kPrefetch]);
+#endif
       static_for<PT>([&](auto t_c) {
         constexpr int t = decltype(t_c)::value;
         if constexpr (k < KH) acc[t] = mfma48<F>(a, bh[t][k], acc[t]);
         else acc[t] = mfma48<F>(a, bp(t, k - KH), acc[t]);
       });
       pipe.template prefetch<pos>();
+#ifdef DN_PIPE_ASM_READS
+      if constexpr (k == KT - 2) {
+        if constexpr (nt + 1 < NT_OUT) pipe.template bias_prefetch<(nt + 1) * 64>(bias_addr);
+        else if constexpr (LAST) pipe.template bias_prefetch<0>(next_addr);
+        else pipe.template bias_prefetch<NT_OUT * 64>(bias_addr);
+      }
+#else
       __builtin_amdgcn_sched_group_barrier(0x008, PT, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#endif
     });
     __builtin_amdgcn_sched_barrier(0);
     static_for<PT>([&](auto t_c) { emit(nt_c, t_c, acc[decltype(t_c)::value]); });
   });
+#ifdef DN_PIPE_ASM_READS
+  pipe.settle();   // no read stays in flight across a stage boundary (control flow merges there: see Pipe::settle)
+#endif
 }
 
 // rows 4g..4g+3 of output tile NT -> elements (NT & 1) * 4 .. + 3 of B piece NT / 2 (g48_hidden_col)
@@ -182,12 +213,22 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   pipe.slot_nxt = 0;
+  // this lane group's 4 rows of bias tile 0 (LDS byte address; the stages add tile offsets)
+  // (rebuilt at every use from an opaque copy of the thread index - see fresh_lane - instead of being carried in a VGPR)
+  auto bias_at = [&](int tile) { return pipe.ring_addr + kRingBytes + ((fresh_lane() >> 4) << 4) + tile * 64; };
+#ifdef DN_PIPE_ASM_READS
+  static_assert(kPrefetch == 2, "wait counts in run_stage48 are written for a two-piece FIFO");
+  pipe.rda_cur = pipe.ring_addr + lane * 16;
+  pipe.slot_cur_base = pipe.ring_addr;       // phase 0 lives in slot 0: phase_begin() of phase 0 turns this into rda_cur
+  pipe.template prologue_read<0>();
+  pipe.template bias_prefetch<0>(bias_at(0));    // same order as in steady state: A(0), bias, A(1)
+  pipe.template prologue_read<1>();
+#else
   pipe.rd_cur = ring + lane * 16;
   pipe.rd_nxt = ring + lane * 16;
 #pragma unroll
   for (int e = 0; e < kPrefetch; ++e) pipe.af[e] = *reinterpret_cast<const f32x4*>(pipe.rd_nxt + e * kPieceBytes);
-
-  const char* bias_g = bias_lds + (lane >> 4) * 16;  // this lane group's 4 rows of bias tile 0
+#endif
 
   int vset = 0;  // which view-direction rows hold this tile's directions (wave-uniform, flips every tile)
   const int n_tiles = static_cast<int>(p.n_tiles);
@@ -232,7 +273,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     BP8 none[PT][1];
     int bias_tile = 0;
     // ---- layer1: xyz encoding -> W, no activation (models.py:238) ----
-    run_stage48<F, NT, 0, KXP, 0>(pipe, none, pe_xyz, bias_g, [&](auto nt_c, auto t_c, const f32x4& acc) {
+    run_stage48<F, NT, 0, KXP, 0>(pipe, none, pe_xyz, bias_at(0), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
       emit48<F, false, decltype(nt_c)::value>(acc, ba[decltype(t_c)::value]);
     });
     bias_tile += NT;
@@ -241,8 +282,8 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       auto emit = [&](auto nt_c, auto t_c, const f32x4& acc) {
         emit48<F, true, decltype(nt_c)::value>(acc, bout[decltype(t_c)::value]);
       };
-      if ((p.skip_mask >> i) & 1u) run_stage48<F, NT, KH, KXP, 0>(pipe, bin, pe_xyz, bias_g + bias_tile * 64, emit);
-      else run_stage48<F, NT, KH, 0, 0>(pipe, bin, no_pe, bias_g + bias_tile * 64, emit);
+      if ((p.skip_mask >> i) & 1u) run_stage48<F, NT, KH, KXP, 0>(pipe, bin, pe_xyz, bias_at(bias_tile), 0u, emit);
+      else run_stage48<F, NT, KH, 0, 0>(pipe, bin, no_pe, bias_at(bias_tile), 0u, emit);
       bias_tile += NT;
     };
     int i = 0;
@@ -260,10 +301,10 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     float out4[PT][4];
     if (p.use_viewdirs) {
       // ---- fc_alpha (its own 16-row tile, row 0, streamed first) + fc_feat with ReLU (models.py:248-249) ----
-      run_stage48<F, 1, KH, 0, 0>(pipe, ba, no_pe, bias_g + bias_tile * 64, [&](auto, auto t_c, const f32x4& acc) {
+      run_stage48<F, 1, KH, 0, 0>(pipe, ba, no_pe, bias_at(bias_tile), 0u, [&](auto, auto t_c, const f32x4& acc) {
         out4[decltype(t_c)::value][3] = acc[0];  // row 0 lives in lane group 0, register 0
       });
-      run_stage48<F, NT, KH, 0, KH % kPhasePieces>(pipe, ba, no_pe, bias_g + (bias_tile + 1) * 64, [&](auto nt_c, auto t_c, const f32x4& acc) {
+      run_stage48<F, NT, KH, 0, KH % kPhasePieces>(pipe, ba, no_pe, bias_at(bias_tile + 1), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
         emit48<F, true, decltype(nt_c)::value>(acc, bb[decltype(t_c)::value]);
       });
       bias_tile += NT + 1;
@@ -296,13 +337,13 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       constexpr int POS_D = ((NT + 1) * KH) % kPhasePieces;
       BP8 bg[PT][KH / 2];
       auto pe_dir = [&](int t, int) { return *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes); };
-      run_stage48<F, NT / 2, KH, KDP, POS_D>(pipe, bb, pe_dir, bias_g + bias_tile * 64, [&](auto nt_c, auto t_c, const f32x4& acc) {
+      run_stage48<F, NT / 2, KH, KDP, POS_D>(pipe, bb, pe_dir, bias_at(bias_tile), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
         emit48<F, true, decltype(nt_c)::value>(acc, bg[decltype(t_c)::value]);
       });
       bias_tile += NT / 2;
       // ---- fc_rgb (models.py:253) ----
       constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % kPhasePieces;
-      run_stage48<F, 1, KH / 2, 0, POS_R>(pipe, bg, no_pe, bias_g + bias_tile * 64, [&](auto, auto t_c, const f32x4& acc) {
+      run_stage48<F, 1, KH / 2, 0, POS_R, true>(pipe, bg, no_pe, bias_at(bias_tile), bias_at(0), [&](auto, auto t_c, const f32x4& acc) {
         constexpr int t = decltype(t_c)::value;
         out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2];
       });
@@ -311,7 +352,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       if constexpr (END % kPhasePieces != 0) pipe.template skip<END, kPhasePieces - END>();
     } else {
       // ---- fc_out (models.py:256) ----
-      run_stage48<F, 1, KH, 0, 0>(pipe, ba, no_pe, bias_g + bias_tile * 64, [&](auto, auto t_c, const f32x4& acc) {
+      run_stage48<F, 1, KH, 0, 0, true>(pipe, ba, no_pe, bias_at(bias_tile), bias_at(0), [&](auto, auto t_c, const f32x4& acc) {
         constexpr int t = decltype(t_c)::value;
         out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2]; out4[t][3] = acc[3];
       });

@@ -13,7 +13,7 @@
 #if !defined(DN_ABLATION_BUILD) && \
     (defined(DN_EXP_NODMA) || defined(DN_EXP_NOREAD) || defined(DN_EXP_SHALLOW) || defined(DN_EXP_LOOSEWAIT) ||    \
      defined(DN_EXP_NOBARRIER) || defined(DN_EXP_REGSTAGE) || defined(DN_EXP_ROTATE) || defined(DN_EXP_SETPRIO) || \
-     defined(DN_EXP_NOPIN) || defined(DN_EXP_NOSAVE) || defined(DN_STORE_POLICY_ID))
+     defined(DN_EXP_NOPIN) || defined(DN_EXP_NOSAVE) || defined(DN_EXP_NOSETTLE) || defined(DN_STORE_POLICY_ID))
 #error "DN_EXP_* / DN_STORE_POLICY_ID are ablation hooks: build them with scripts/build_exp.sh (-DDN_ABLATION_BUILD), never into libdexnerf_hip.so"
 #endif
 
@@ -290,7 +290,8 @@ struct Pipe {
       static_assert(pos % kPhasePieces != 0 || decltype(i_c)::value == 0, "padding never crosses a phase");
       if constexpr (pos % kPhasePieces == kPhasePieces / 2) mid_phase();
 #ifdef DN_PIPE_ASM_READS
-      // only the last kPrefetch skipped positions fetch pieces that will be consumed (the first pieces of the next pass)
+      // only the last kPrefetch skipped positions fetch pieces that will be consumed (the first pieces of the next pass);
+      // with fewer padding pieces than FIFO entries the stage before has already fetched the rest (run_stage48, PAD)
       if constexpr (decltype(i_c)::value >= N - kPrefetch) prefetch<pos>();
 #else
       prefetch<pos>();
@@ -343,9 +344,15 @@ struct Pipe {
   // (phi copies) - before the data has arrived, if a read were still in flight there.  Called at the end of every stage
   // and after the padding pieces: one exposed LDS round trip per stage (12 per 1184 pieces).
   __device__ __forceinline__ void settle() {
-    static_assert(kPrefetch == 2, "settle() names both FIFO entries");
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bias_nxt));
+#ifdef DN_EXP_NOSETTLE   // timing experiment only (UNSAFE: phi copies may read fragments in flight)
+    return;
+#endif
+    static_assert(kPrefetch == 2 || kPrefetch == 3, "settle() names every FIFO entry");
+    if constexpr (kPrefetch == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bias_nxt));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[kPrefetch - 1]), "+v"(bias_nxt));
   }
+#else
+  __device__ __forceinline__ void settle() {}
 #endif
 };
 

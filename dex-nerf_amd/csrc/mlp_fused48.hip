@@ -26,13 +26,23 @@ __device__ __forceinline__ f32x4 mfma48(typename Prec<F>::BPiece a, typename Pre
   else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// how many of the pieces [q0, q1) of the stream are ever fetched: all, except - behind the LAST stage of a pass, which ends at
+// position END - the PAD padding pieces nobody consumes
+template <bool LAST, int END, int PAD>
+constexpr int g48_issued(int q0, int q1) {
+  int n = 0;
+  for (int q = q0; q < q1; ++q) n += (LAST && q >= END && q < END + PAD) ? 0 : 1;
+  return n;
+}
+
 // One GEMM stage: NT_OUT 16-row output tiles, KH hidden pieces + KP encoding pieces per tile, three point groups.
 // bias_addr: LDS byte address of this lane group's 16 bytes of the stage's bias tile 0; the bias tiles of a tile pass are
 // contiguous in stream order, so "the next tile's bias" is the next 64 bytes, except after the last stage of the pass
 // (LAST): there it is next_addr (tile 0 of layer1).  Read pipeline (DN_PIPE_ASM_READS): step k of a tile = take A(p),
 // three MFMAs, read A(p+2); the next tile's bias read goes out right after the A read of step KT-2, i.e. between A(next
-// tile, 0) and A(next tile, 1) - so the wait counts are 1 everywhere (at k = 0 that covers the bias too) and 2 at k = KT-1.
-template <int F, int NT_OUT, int KH, int KP, int POS0, bool LAST = false, class PipeT, class BH, class BP, class Emit>
+// tile, 0) and A(next tile, 1) - so with a FIFO of P pieces the wait counts are P - 1 everywhere and P at k = KT-1; the
+// bias take at k = 0 waits with 1 (one A read was issued after the bias read), which also lands every older A read.
+template <int F, int NT_OUT, int KH, int KP, int POS0, bool LAST = false, bool SETTLE = true, int PAD = 0, class PipeT, class BH, class BP, class Emit>
 __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, unsigned bias_addr, unsigned next_addr, Emit&& emit) {
   constexpr int PT = 3, KT = KH + KP;
   static_assert(KT >= 2, "the bias prefetch distance assumes at least two pieces per tile");
@@ -50,7 +60,10 @@ __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, 
 #pragma unroll
         for (int t = 0; t < PT; ++t) acc[t] = b;
       }
-      const auto a = __builtin_bit_cast(typename Prec<F>::BPiece, pipe.template take<pos, (k == KT - 1) ? 2 : 1>());
+      // younger reads of ours than A(pos): the other FIFO entries - those that were issued at all (see PAD below) - plus
+      // the next tile's bias at k = KT - 1
+      constexpr int newer = g48_issued<LAST, POS0 + NT_OUT * KT, PAD>(pos + 1, pos + kPrefetch) + (k == KT - 1 ? 1 : 0);
+      const auto a = __builtin_bit_cast(typename Prec<F>::BPiece, pipe.template take<pos, newer>());
 #else
       if constexpr (k == 0) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(pipe.ring + (bias_addr - pipe.ring_addr) + nt * 64);
@@ -64,7 +77,13 @@ __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, 
         if constexpr (k < KH) acc[t] = mfma48<F>(a, bh[t][k], acc[t]);
         else acc[t] = mfma48<F>(a, bp(t, k - KH), acc[t]);
       });
+#ifdef DN_PIPE_ASM_READS
+      // PAD padding pieces follow the last stage of a pass (Pipe::skip): a read of one of THOSE would never be consumed, and
+      // a fragment nobody consumes is a dead value to the compiler - it reuses the registers while the read is in flight
+      if constexpr (g48_issued<LAST, POS0 + NT_OUT * KT, PAD>(pos + kPrefetch, pos + kPrefetch + 1) == 1) pipe.template prefetch<pos>();
+#else
       pipe.template prefetch<pos>();
+#endif
 #ifdef DN_PIPE_ASM_READS
       if constexpr (k == KT - 2) {
         if constexpr (nt + 1 < NT_OUT) pipe.template bias_prefetch<(nt + 1) * 64>(bias_addr);
@@ -80,7 +99,9 @@ __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, 
     static_for<PT>([&](auto t_c) { emit(nt_c, t_c, acc[decltype(t_c)::value]); });
   });
 #ifdef DN_PIPE_ASM_READS
-  pipe.settle();   // no read stays in flight across a stage boundary (control flow merges there: see Pipe::settle)
+  // run-time network shape: no read stays in flight across a stage boundary (control flow merges there: see Pipe::settle);
+  // the fixed-shape instances are straight-line code from the top of a tile pass to its end and settle once, there
+  if constexpr (SETTLE) pipe.settle();
 #endif
 }
 
@@ -129,8 +150,15 @@ __device__ __forceinline__ void rotate3(const float (&x)[3], int g, float (&xr)[
   xr[2] = __uint_as_float(b2 ^ ((b2 ^ b0) & m1) ^ ((b2 ^ b1) & m2));
 }
 
-template <int W, int F>
+// DC / MASKC / VIEWC > 0: depth, skip mask and view-direction branch fixed at compile time - the whole tile pass is then
+// straight-line code: no control-flow merge for the compiler to place copies of in-flight fragments at (Pipe::settle), the
+// ring bookkeeping stays in SGPRs, and the epilogue of a stage's last tile overlaps the next stage's first MFMAs like any
+// other tile's (measured: the 12 per-stage settles + merges of the run-time form cost 5 % of the launch).  DC = 0: everything
+// run-time (p.D, p.skip_mask, p.use_viewdirs), one settle per stage.
+template <int W, int F, int DC = 0, unsigned MASKC = 0, int VIEWC = 0>
 __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdParams p, G48Params q) {
+  constexpr bool FIXED = DC > 0;
+  constexpr bool ST = !FIXED;   // settle at stage ends
   using BP8 = typename Prec<F>::BPiece;
   using Elem = typename Prec<F>::Elem;
   constexpr int PT = 3;
@@ -217,12 +245,11 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
   // (rebuilt at every use from an opaque copy of the thread index - see fresh_lane - instead of being carried in a VGPR)
   auto bias_at = [&](int tile) { return pipe.ring_addr + kRingBytes + ((fresh_lane() >> 4) << 4) + tile * 64; };
 #ifdef DN_PIPE_ASM_READS
-  static_assert(kPrefetch == 2, "wait counts in run_stage48 are written for a two-piece FIFO");
   pipe.rda_cur = pipe.ring_addr + lane * 16;
   pipe.slot_cur_base = pipe.ring_addr;       // phase 0 lives in slot 0: phase_begin() of phase 0 turns this into rda_cur
-  pipe.template prologue_read<0>();
-  pipe.template bias_prefetch<0>(bias_at(0));    // same order as in steady state: A(0), bias, A(1)
-  pipe.template prologue_read<1>();
+  static_for<kPrefetch - 1>([&](auto e_c) { pipe.template prologue_read<decltype(e_c)::value>(); });
+  pipe.template bias_prefetch<0>(bias_at(0));    // same order as in steady state: ..., bias, one more A read
+  pipe.template prologue_read<kPrefetch - 1>();
 #else
   pipe.rd_cur = ring + lane * 16;
   pipe.rd_nxt = ring + lane * 16;
@@ -273,90 +300,112 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     BP8 none[PT][1];
     int bias_tile = 0;
     // ---- layer1: xyz encoding -> W, no activation (models.py:238) ----
-    run_stage48<F, NT, 0, KXP, 0>(pipe, none, pe_xyz, bias_at(0), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
+    run_stage48<F, NT, 0, KXP, 0, false, ST>(pipe, none, pe_xyz, bias_at(0), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
       emit48<F, false, decltype(nt_c)::value>(acc, ba[decltype(t_c)::value]);
     });
     bias_tile += NT;
-    // ---- trunk (models.py:239-246), two layers per iteration: the activations ping-pong between two register sets ----
-    auto trunk_layer = [&](int i, const BP8 (&bin)[PT][KH], BP8 (&bout)[PT][KH]) __attribute__((always_inline)) {
-      auto emit = [&](auto nt_c, auto t_c, const f32x4& acc) {
-        emit48<F, true, decltype(nt_c)::value>(acc, bout[decltype(t_c)::value]);
-      };
-      if ((p.skip_mask >> i) & 1u) run_stage48<F, NT, KH, KXP, 0>(pipe, bin, pe_xyz, bias_at(bias_tile), 0u, emit);
-      else run_stage48<F, NT, KH, 0, 0>(pipe, bin, no_pe, bias_at(bias_tile), 0u, emit);
-      bias_tile += NT;
-    };
-    int i = 0;
-    for (; i + 1 < p.D - 1; i += 2) {
-      trunk_layer(i, ba, bb);
-      trunk_layer(i + 1, bb, ba);
-    }
-    if (i < p.D - 1) {
-      trunk_layer(i, ba, bb);
-#pragma unroll
-      for (int t = 0; t < PT; ++t)
-#pragma unroll
-        for (int k = 0; k < KH; ++k) ba[t][k] = bb[t][k];
-    }
     float out4[PT][4];
-    if (p.use_viewdirs) {
-      // ---- fc_alpha (its own 16-row tile, row 0, streamed first) + fc_feat with ReLU (models.py:248-249) ----
-      run_stage48<F, 1, KH, 0, 0>(pipe, ba, no_pe, bias_at(bias_tile), 0u, [&](auto, auto t_c, const f32x4& acc) {
-        out4[decltype(t_c)::value][3] = acc[0];  // row 0 lives in lane group 0, register 0
-      });
-      run_stage48<F, NT, KH, 0, KH % kPhasePieces>(pipe, ba, no_pe, bias_at(bias_tile + 1), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
-        emit48<F, true, decltype(nt_c)::value>(acc, bb[decltype(t_c)::value]);
-      });
-      bias_tile += NT + 1;
-      // ---- view-direction encoding (one 32-deep piece per point group) ----
-      // fenced on both sides: interleaved into the fc_feat MFMAs its temporaries push finished activation pieces to scratch
-      __builtin_amdgcn_sched_barrier(0);
-      // (one point group at a time, into the xyz stash - dead once the trunk is done - so that neither the block's
-      // temporaries nor the pieces themselves compete with the 96 registers of fc_feat's output)
-      {
-        const int ln = fresh_lane();
-        const int j = ln & 15;
-        const f32x4* tabd = reinterpret_cast<const f32x4*>(tab_lds + 1024) + (ln >> 4) * 8;
-        char* pex = pex_of(ln);
-        static_for<PT>([&](auto t_c) {
-          constexpr int t = decltype(t_c)::value;
-          float v[3];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) v[c] = inbuf[(7 + 3 * vset + c) * PPW + t * 16 + j];
-          float vr[3];
-          rotate3(v, ln >> 4, vr);
-          BP8 piece;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) piece[e] = static_cast<Elem>(pe_value(vr[e % 3], tabd[e]));
-          *reinterpret_cast<BP8*>(pex + t * kPieceBytes) = piece;
-          __builtin_amdgcn_sched_barrier(0);
+    // ---- heads on the trunk output hx (hy: the other, by then free, activation set) ----
+    auto heads = [&](const BP8 (&hx)[PT][KH], BP8 (&hy)[PT][KH], auto view_c) __attribute__((always_inline)) {
+      if constexpr (decltype(view_c)::value) {
+        // ---- fc_alpha (its own 16-row tile, row 0, streamed first) + fc_feat with ReLU (models.py:248-249) ----
+        run_stage48<F, 1, KH, 0, 0, false, ST>(pipe, hx, no_pe, bias_at(bias_tile), 0u, [&](auto, auto t_c, const f32x4& acc) {
+          out4[decltype(t_c)::value][3] = acc[0];  // row 0 lives in lane group 0, register 0
         });
+        run_stage48<F, NT, KH, 0, KH % kPhasePieces, false, ST>(pipe, hx, no_pe, bias_at(bias_tile + 1), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
+          emit48<F, true, decltype(nt_c)::value>(acc, hy[decltype(t_c)::value]);
+        });
+        bias_tile += NT + 1;
+        // ---- view-direction encoding (one 32-deep piece per point group) ----
+        // fenced on both sides: interleaved into the fc_feat MFMAs its temporaries push finished activation pieces to scratch
+        __builtin_amdgcn_sched_barrier(0);
+        // (one point group at a time, into the xyz stash - dead once the trunk is done - so that neither the block's
+        // temporaries nor the pieces themselves compete with the 96 registers of fc_feat's output)
+        {
+          const int ln = fresh_lane();
+          const int j = ln & 15;
+          const f32x4* tabd = reinterpret_cast<const f32x4*>(tab_lds + 1024) + (ln >> 4) * 8;
+          char* pex = pex_of(ln);
+          static_for<PT>([&](auto t_c) {
+            constexpr int t = decltype(t_c)::value;
+            float v[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = inbuf[(7 + 3 * vset + c) * PPW + t * 16 + j];
+            float vr[3];
+            rotate3(v, ln >> 4, vr);
+            BP8 piece;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) piece[e] = static_cast<Elem>(pe_value(vr[e % 3], tabd[e]));
+            *reinterpret_cast<BP8*>(pex + t * kPieceBytes) = piece;
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- layers_dir[0] on cat(feat, view) -> W/2, ReLU (models.py:250-252) ----
+        constexpr int POS_D = ((NT + 1) * KH) % kPhasePieces;
+        BP8 bg[PT][KH / 2];
+        auto pe_dir = [&](int t, int) { return *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes); };
+        run_stage48<F, NT / 2, KH, KDP, POS_D, false, ST>(pipe, hy, pe_dir, bias_at(bias_tile), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
+          emit48<F, true, decltype(nt_c)::value>(acc, bg[decltype(t_c)::value]);
+        });
+        bias_tile += NT / 2;
+        // ---- fc_rgb (models.py:253) ----
+        constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % kPhasePieces;
+        constexpr int END = POS_R + KH / 2;
+        static_assert(END <= kPhasePieces, "the tail stays inside one phase");
+        run_stage48<F, 1, KH / 2, 0, POS_R, true, ST, (kPhasePieces - END) % kPhasePieces>(pipe, bg, no_pe, bias_at(bias_tile), bias_at(0), [&](auto, auto t_c, const f32x4& acc) {
+          constexpr int t = decltype(t_c)::value;
+          out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2];
+        });
+        if constexpr (END % kPhasePieces != 0) pipe.template skip<END, kPhasePieces - END>();   // (settles at its end)
+        else pipe.settle();
+      } else {
+        // ---- fc_out (models.py:256) ----
+        run_stage48<F, 1, KH, 0, 0, true, ST, (kPhasePieces - KH % kPhasePieces) % kPhasePieces>(pipe, hx, no_pe, bias_at(bias_tile), bias_at(0), [&](auto, auto t_c, const f32x4& acc) {
+          constexpr int t = decltype(t_c)::value;
+          out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2]; out4[t][3] = acc[3];
+        });
+        if constexpr (KH % kPhasePieces != 0) pipe.template skip<KH % kPhasePieces, kPhasePieces - KH % kPhasePieces>();
+        else pipe.settle();
       }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- layers_dir[0] on cat(feat, view) -> W/2, ReLU (models.py:250-252) ----
-      constexpr int POS_D = ((NT + 1) * KH) % kPhasePieces;
-      BP8 bg[PT][KH / 2];
-      auto pe_dir = [&](int t, int) { return *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes); };
-      run_stage48<F, NT / 2, KH, KDP, POS_D>(pipe, bb, pe_dir, bias_at(bias_tile), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
-        emit48<F, true, decltype(nt_c)::value>(acc, bg[decltype(t_c)::value]);
+    };
+    // ---- trunk (models.py:239-246): the activations ping-pong between two register sets ----
+    if constexpr (FIXED) {
+      static_for<DC - 1>([&](auto i_c) {
+        constexpr int i = decltype(i_c)::value;
+        auto& bin = (i % 2 == 0) ? ba : bb;
+        auto& bout = (i % 2 == 0) ? bb : ba;
+        auto emit = [&](auto nt_c, auto t_c, const f32x4& acc) { emit48<F, true, decltype(nt_c)::value>(acc, bout[decltype(t_c)::value]); };
+        if constexpr ((MASKC >> i) & 1u) run_stage48<F, NT, KH, KXP, 0, false, false>(pipe, bin, pe_xyz, bias_at(bias_tile), 0u, emit);
+        else run_stage48<F, NT, KH, 0, 0, false, false>(pipe, bin, no_pe, bias_at(bias_tile), 0u, emit);
+        bias_tile += NT;
       });
-      bias_tile += NT / 2;
-      // ---- fc_rgb (models.py:253) ----
-      constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % kPhasePieces;
-      run_stage48<F, 1, KH / 2, 0, POS_R, true>(pipe, bg, no_pe, bias_at(bias_tile), bias_at(0), [&](auto, auto t_c, const f32x4& acc) {
-        constexpr int t = decltype(t_c)::value;
-        out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2];
-      });
-      constexpr int END = POS_R + KH / 2;
-      static_assert(END <= kPhasePieces, "the tail stays inside one phase");
-      if constexpr (END % kPhasePieces != 0) pipe.template skip<END, kPhasePieces - END>();
+      if constexpr ((DC - 1) % 2 == 0) heads(ba, bb, std::integral_constant<bool, VIEWC != 0>{});
+      else heads(bb, ba, std::integral_constant<bool, VIEWC != 0>{});
     } else {
-      // ---- fc_out (models.py:256) ----
-      run_stage48<F, 1, KH, 0, 0, true>(pipe, ba, no_pe, bias_at(bias_tile), bias_at(0), [&](auto, auto t_c, const f32x4& acc) {
-        constexpr int t = decltype(t_c)::value;
-        out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2]; out4[t][3] = acc[3];
-      });
-      if constexpr (KH % kPhasePieces != 0) pipe.template skip<KH % kPhasePieces, kPhasePieces - KH % kPhasePieces>();
+      // two layers per iteration of a run-time loop
+      auto trunk_layer = [&](int i, const BP8 (&bin)[PT][KH], BP8 (&bout)[PT][KH]) __attribute__((always_inline)) {
+        auto emit = [&](auto nt_c, auto t_c, const f32x4& acc) {
+          emit48<F, true, decltype(nt_c)::value>(acc, bout[decltype(t_c)::value]);
+        };
+        if ((p.skip_mask >> i) & 1u) run_stage48<F, NT, KH, KXP, 0>(pipe, bin, pe_xyz, bias_at(bias_tile), 0u, emit);
+        else run_stage48<F, NT, KH, 0, 0>(pipe, bin, no_pe, bias_at(bias_tile), 0u, emit);
+        bias_tile += NT;
+      };
+      int i = 0;
+      for (; i + 1 < p.D - 1; i += 2) {
+        trunk_layer(i, ba, bb);
+        trunk_layer(i + 1, bb, ba);
+      }
+      if (i < p.D - 1) {
+        trunk_layer(i, ba, bb);
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+          for (int k = 0; k < KH; ++k) ba[t][k] = bb[t][k];
+      }
+      if (p.use_viewdirs) heads(ba, bb, std::true_type{});
+      else heads(ba, bb, std::false_type{});
     }
     const int lo = fresh_lane();
 #pragma unroll
@@ -480,8 +529,18 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(kG48Waves * 64), lds, stream, p, q);
     return check_launch("mlp_forward48");
   };
-  if (precision == DN_PREC_F16)
+  // fixed-shape instances: the paper network (D8 / W256 / skip 4, view directions - BASELINE configs 2, 4, 5) and the fork's
+  // as-shipped 4 x 128 nets (config 3); everything else runs the run-time-shape kernel
+  const bool paper = d.hidden_size == 256 && d.num_layers == 8 && L.skip_mask == 0x10u && d.use_viewdirs;
+  const bool shipped = d.hidden_size == 128 && d.num_layers == 4 && L.skip_mask == 0u && d.use_viewdirs;
+  const bool fixed_ok = std::getenv("DEXNERF_G48_RUNTIME_SHAPE") == nullptr;
+  if (precision == DN_PREC_F16) {
+    if (paper && fixed_ok) return launch(mlp_forward48_kernel<256, 2, 8, 0x10u, 1>);
+    if (shipped && fixed_ok) return launch(mlp_forward48_kernel<128, 2, 4, 0u, 1>);
     return d.hidden_size == 256 ? launch(mlp_forward48_kernel<256, 2>) : launch(mlp_forward48_kernel<128, 2>);
+  }
+  if (paper && fixed_ok) return launch(mlp_forward48_kernel<256, 1, 8, 0x10u, 1>);
+  if (shipped && fixed_ok) return launch(mlp_forward48_kernel<128, 1, 4, 0u, 1>);
   return d.hidden_size == 256 ? launch(mlp_forward48_kernel<256, 1>) : launch(mlp_forward48_kernel<128, 1>);
 }
 

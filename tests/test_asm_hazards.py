@@ -72,8 +72,8 @@ def test_explicit_lds_read_pipeline_is_not_touched_in_flight(kernels):
         assert not bad, (name, bad[:4])
         # the pipeline is really the explicit one: counted waits dominate, the hot loop has no lgkmcnt(0) after a fresh read
         counted = sum(1 for line in ins if line.startswith("s_waitcnt lgkmcnt(1)") or line.startswith("s_waitcnt lgkmcnt(2)"))
-        assert counted > 300, (name, counted)
-    assert seen == 4
+        assert counted > 150, (name, counted)
+    assert seen == 8
 
 
 def test_the_checkers_catch_planted_hazards():

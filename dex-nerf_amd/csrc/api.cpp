@@ -45,11 +45,11 @@ int device_cus() {
 static size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
 
 struct Workspace {
-  float *z_c, *rf_c, *w_c, *z_f, *rf_f;
+  float *z_c, *rf_c, *w_c, *z_f, *rf_f, *g_rf;
   size_t bytes;
 };
 
-static Workspace carve(void* base, int64_t n, int nc, int nf) {
+static Workspace carve(void* base, int64_t n, int nc, int nf, bool train = false) {
   Workspace w{};
   size_t off = 0;
   auto take = [&](size_t floats) {
@@ -64,6 +64,7 @@ static Workspace carve(void* base, int64_t n, int nc, int nf) {
     w.z_f = take(static_cast<size_t>(n) * (nc + nf));
     w.rf_f = take(static_cast<size_t>(n) * (nc + nf) * 4);
   }
+  if (train) w.g_rf = take(static_cast<size_t>(n) * (nc + nf) * 4);   // d loss / d raw radiance field, one network at a time
   w.bytes = off;
   return w;
 }
@@ -112,4 +113,83 @@ extern "C" int dn_render_rays(const dn_mlp_desc* desc_coarse, const void* packed
     return rc;
   return dn_volume_render(w.rf_f, w.z_f, rays + 3, ray_stride, noise_f, noise_std, white_background, h_m_thres, n_thres,
                           n_rays, num_coarse + num_fine, rgb_f, nullptr, acc_f, nullptr, depth_f, dex_f, stream);
+}
+
+// ---- predict_and_render_radiance under autograd (reference nerf/train_utils.py:92-202 + loss.backward(),
+// train_dexnerf_rgb.py:278): one call forward, one call backward -------------------------------------------------------
+extern "C" size_t dn_render_train_workspace_bytes(int64_t n_rays, int num_coarse, int num_fine) {
+  if (n_rays < 0 || num_coarse < 1 || num_fine < 0) return 0;
+  return carve(nullptr, n_rays, num_coarse, num_fine, true).bytes;
+}
+
+extern "C" int dn_render_rays_train(const dn_mlp_desc* desc_coarse, const void* packed_coarse, const dn_mlp_desc* desc_fine,
+                                    const void* packed_fine, int precision, const float* rays, int ray_stride,
+                                    int64_t n_rays, int num_coarse, int num_fine, int lindisp, float noise_std,
+                                    int white_background, const float* h_m_thres, int n_thres, const float* t_rand,
+                                    const float* noise_c, const float* u, const float* noise_f, float* rgb_c,
+                                    float* depth_c, float* acc_c, float* rgb_f, float* depth_f, float* acc_f, float* dex_f,
+                                    void* workspace, void* act_c, void* masks_c, void* act_f, void* masks_f,
+                                    dn_stream_t stream) {
+  if (n_rays == 0) return 0;
+  DN_REQUIRE(desc_coarse && packed_coarse && rays && workspace && act_c && masks_c && n_rays >= 0, "dn_render_rays_train: bad arguments");
+  DN_REQUIRE(num_fine == 0 || (desc_fine && packed_fine && act_f && masks_f), "dn_render_rays_train: fine pass requested without a fine net / its buffers");
+  DN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "dn_render_rays_train: workspace must be 256-byte aligned");
+  Workspace w = carve(workspace, n_rays, num_coarse, num_fine, true);
+  int rc;
+  if ((rc = dn_coarse_depths(rays, ray_stride, n_rays, num_coarse, lindisp, t_rand, w.z_c, stream))) return rc;
+  if ((rc = dn_run_network_train(desc_coarse, precision, packed_coarse, nullptr, nullptr, rays, ray_stride, w.z_c, n_rays,
+                                 num_coarse, w.rf_c, act_c, masks_c, stream)))
+    return rc;
+  const bool fine = num_fine > 0;
+  if ((rc = dn_volume_render(w.rf_c, w.z_c, rays + 3, ray_stride, noise_c, noise_std, white_background, h_m_thres,
+                             fine ? 0 : n_thres, n_rays, num_coarse, rgb_c, nullptr, acc_c, w.w_c, depth_c,
+                             fine ? nullptr : dex_f, stream)))
+    return rc;
+  if (!fine) return 0;
+  if ((rc = dn_fine_depths(w.z_c, w.w_c, u, n_rays, num_coarse, num_fine, w.z_f, nullptr, stream))) return rc;
+  if ((rc = dn_run_network_train(desc_fine, precision, packed_fine, nullptr, nullptr, rays, ray_stride, w.z_f, n_rays,
+                                 num_coarse + num_fine, w.rf_f, act_f, masks_f, stream)))
+    return rc;
+  return dn_volume_render(w.rf_f, w.z_f, rays + 3, ray_stride, noise_f, noise_std, white_background, h_m_thres, n_thres,
+                          n_rays, num_coarse + num_fine, rgb_f, nullptr, acc_f, nullptr, depth_f, dex_f, stream);
+}
+
+extern "C" int dn_render_rays_backward(const dn_mlp_desc* desc_coarse, const void* packed_bwd_coarse,
+                                       const dn_mlp_desc* desc_fine, const void* packed_bwd_fine, int precision,
+                                       const float* rays, int ray_stride, int64_t n_rays, int num_coarse, int num_fine,
+                                       float noise_std, int white_background, const float* noise_c, const float* noise_f,
+                                       const float* g_rgb_c, const float* g_depth_c, const float* g_acc_c,
+                                       const float* g_rgb_f, const float* g_depth_f, const float* g_acc_f, void* workspace,
+                                       const void* act_c, const void* masks_c, void* grads_c, const void* act_f,
+                                       const void* masks_f, void* grads_f, float* const* h_dW_c, float* const* h_db_c,
+                                       float* const* h_dW_f, float* const* h_db_f, int nets, dn_stream_t stream) {
+  if (n_rays == 0) return 0;
+  DN_REQUIRE(rays && workspace && n_rays >= 0 && (nets & ~3) == 0, "dn_render_rays_backward: bad arguments");
+  DN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "dn_render_rays_backward: workspace must be 256-byte aligned");
+  Workspace w = carve(workspace, n_rays, num_coarse, num_fine, true);
+  int rc;
+  auto half = [&](const dn_mlp_desc* desc, const void* packed_bwd, const float* rf, const float* z, int samples,
+                  const float* noise, const float* g_rgb, const float* g_depth, const float* g_acc, const void* act,
+                  const void* masks, void* grads, float* const* h_dW, float* const* h_db) -> int {
+    DN_REQUIRE(desc && packed_bwd && act && masks && grads && h_dW && h_db, "dn_render_rays_backward: a network's buffers are missing");
+    if ((rc = dn_volume_render_backward(rf, z, rays + 3, ray_stride, noise, noise_std, white_background, n_rays, samples,
+                                        g_rgb, g_depth, g_acc, nullptr, nullptr, w.g_rf, stream)))
+      return rc;
+    const int64_t n_points = n_rays * samples;
+    if ((rc = dn_mlp_backward_data(desc, precision, packed_bwd, w.g_rf, masks, n_points, grads, stream))) return rc;
+    return dn_mlp_weight_grad_all(desc, precision, act, grads, n_points, h_dW, h_db, stream);
+  };
+  // the fine network first: autograd's order too (its graph node is the younger one), and the half a data-parallel caller
+  // wants finished first so that its all-reduce overlaps the coarse half
+  if ((nets & 2) && num_fine > 0) {
+    if ((rc = half(desc_fine, packed_bwd_fine, w.rf_f, w.z_f, num_coarse + num_fine, noise_f, g_rgb_f, g_depth_f, g_acc_f,
+                   act_f, masks_f, grads_f, h_dW_f, h_db_f)))
+      return rc;
+  }
+  if (nets & 1) {
+    if ((rc = half(desc_coarse, packed_bwd_coarse, w.rf_c, w.z_c, num_coarse, noise_c, g_rgb_c, g_depth_c, g_acc_c, act_c,
+                   masks_c, grads_c, h_dW_c, h_db_c)))
+      return rc;
+  }
+  return 0;
 }

@@ -13,7 +13,7 @@
 #if !defined(DN_ABLATION_BUILD) && \
     (defined(DN_EXP_NODMA) || defined(DN_EXP_NOREAD) || defined(DN_EXP_SHALLOW) || defined(DN_EXP_LOOSEWAIT) ||    \
      defined(DN_EXP_NOBARRIER) || defined(DN_EXP_REGSTAGE) || defined(DN_EXP_ROTATE) || defined(DN_EXP_SETPRIO) || \
-     defined(DN_EXP_NOPIN) || defined(DN_EXP_NOSAVE) || defined(DN_EXP_NOSETTLE) || defined(DN_STORE_POLICY_ID))
+     defined(DN_EXP_NOPIN) || defined(DN_EXP_NOSAVE) || defined(DN_EXP_NOSETTLE) || defined(DN_STAMP) || defined(DN_STORE_POLICY_ID))
 #error "DN_EXP_* / DN_STORE_POLICY_ID are ablation hooks: build them with scripts/build_exp.sh (-DDN_ABLATION_BUILD), never into libdexnerf_hip.so"
 #endif
 
@@ -130,6 +130,21 @@ struct Pipe {
   // register between its ds_read and its wait.
   unsigned rda_cur;            // 32-bit LDS byte address (+ lane * 16) of the current phase slot; the next slot's is formed
                                // where it is needed (the last kPrefetch pieces of a phase) from the scalar slot base
+#ifdef DN_STAMP   // diagnostic build only: where a wave's cycles go at the phase boundaries (s_memtime, accumulated in SGPRs)
+  unsigned st_vm = 0, st_bar = 0, st_dma = 0, st_seg = 0, st_n = 0, st_prev = 0;
+  unsigned st_sub[4] = {0, 0, 0, 0}, st_last = 0;   // MFMA time of the four quarters of a phase (4 pieces each)
+  template <int I>
+  __device__ __forceinline__ void substamp() {       // at piece 4 * I of a phase, I = 1..3
+    const unsigned t = stamp();
+    st_sub[I - 1] += t - st_last;
+    st_last = t;
+  }
+  __device__ __forceinline__ unsigned stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return __builtin_amdgcn_readfirstlane(static_cast<unsigned>(t));
+  }
+#endif
   unsigned slot_cur_base;      // (scalar) LDS byte address of the slot of the NEXT phase (becomes rda_cur at phase_begin)
   f32x4 bias_nxt;              // bias rows of the NEXT 16-row tile, read two pieces ahead of its first MFMA
 #endif
@@ -238,7 +253,15 @@ struct Pipe {
     // No LDS wait here: every read of the slot being recycled (phase p-1) was waited for by the take() in front of its
     // MFMAs, which precede this point in program order; the reads still in flight belong to phases p and p+1.
     static_assert(PER_WAVE == 2, "the asm-read pipeline is the 8-wave geometry");
+#ifdef DN_STAMP
+    const unsigned st0 = stamp();
+    if (st_n) { st_seg += st0 - st_prev; st_sub[3] += st0 - st_last; }
+#endif
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#ifdef DN_STAMP
+    const unsigned st1 = stamp();
+    st_vm += st1 - st0;
+#endif
 #else
     if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -262,8 +285,18 @@ struct Pipe {
 #ifndef DN_EXP_NOBARRIER   // timing experiment only (UNSAFE: no cross-wave ordering of ring slots)
     __builtin_amdgcn_s_barrier();
 #endif
+#if defined(DN_STAMP) && defined(DN_PIPE_ASM_READS)
+    const unsigned st2 = stamp();
+    st_bar += st2 - st1;
+#endif
     advance_issue();
     dma_phase(pend_src, pend_dst, (WAVES == 4 || wave < 4) ? 1u : 0u);
+#if defined(DN_STAMP) && defined(DN_PIPE_ASM_READS)
+    st_prev = stamp();
+    st_dma += st_prev - st2;
+    st_last = st_prev;
+    ++st_n;
+#endif
 #endif
     slot_nxt = (slot_nxt + 1 == kRingPhases) ? 0 : slot_nxt + 1;
 #ifdef DN_PIPE_ASM_READS
@@ -277,7 +310,16 @@ struct Pipe {
 
   __device__ __forceinline__ void mid_phase() {
 #ifndef DN_EXP_REGSTAGE
+#ifdef DN_STAMP
+    const unsigned m0 = stamp();
+#endif
     if constexpr (WAVES == 8) dma_phase(pend_src, pend_dst, wave >= 4 ? 1u : 0u);
+#ifdef DN_STAMP
+    const unsigned m1 = stamp();
+    st_dma += m1 - m0;
+    st_prev += m1 - m0;   // keep the DMA issue out of the MFMA-segment figure
+    st_last = m1;
+#endif
 #endif
   }
 

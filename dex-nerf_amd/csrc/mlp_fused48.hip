@@ -15,6 +15,8 @@
 #ifndef DN_G48_COMPILER_READS    // (ablation hook: the r01 pipeline with compiler-issued reads and waits)
 #define DN_PIPE_ASM_READS 1      // A-fragment / bias LDS reads and their counted waits as opaque asm (mlp_device.h Pipe)
 #endif
+#include <vector>
+
 #include "mlp_geo48.h"
 
 namespace dn {
@@ -52,6 +54,9 @@ __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, 
     static_for<KT>([&](auto k_c) {
       constexpr int k = decltype(k_c)::value;
       constexpr int pos = POS0 + nt * KT + k;
+#ifdef DN_STAMP
+      if constexpr (pos % 4 == 0 && pos % kPhasePieces != 0) pipe.template substamp<(pos % kPhasePieces) / 4>();
+#endif
       if constexpr (pos % kPhasePieces == 0) pipe.phase_begin();
       if constexpr (pos % kPhasePieces == kPhasePieces / 2) pipe.mid_phase();
 #ifdef DN_PIPE_ASM_READS
@@ -419,6 +424,13 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef DN_STAMP
+  if ((threadIdx.x & 63) == 0) {
+    unsigned* d = q.dbg + (blockIdx.x * WAVES + wave) * 8;
+    d[0] = pipe.st_vm; d[1] = pipe.st_bar; d[2] = pipe.st_dma; d[3] = pipe.st_seg; d[4] = pipe.st_n;
+    d[5] = pipe.st_sub[0]; d[6] = pipe.st_sub[1]; d[7] = pipe.st_sub[2];
+  }
+#endif
 }
 
 // ---- pack: nn.Linear tensors -> bias rows + encoding tables + 16x32 A pieces -----------------------------------
@@ -518,7 +530,8 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
   NetLayout L;
   build_layout48(d, &L);
   FwdParams p = p_in;
-  G48Params q{region, L.bias_bytes, L.total_pieces};
+  G48Params q{};
+  q.base = region; q.bias_bytes = L.bias_bytes; q.total_pieces = L.total_pieces;
   p.n_tiles = (p.n_points + kG48PointsPerWg - 1) / kG48PointsPerWg;
   const size_t lds = g48_lds_bytes(L);
   if (lds > 160 * 1024) { set_error("mlp_forward48: %zu bytes of LDS", lds); return DN_E_UNSUPPORTED; }
@@ -526,7 +539,28 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
   const long long grid = p.n_tiles < cus ? p.n_tiles : cus;
   auto launch = [&](auto kern) -> int {
     if (int rc = ensure_big_lds(reinterpret_cast<const void*>(kern))) return rc;
+#ifdef DN_STAMP   // diagnostic build: synchronous, allocates, prints - never part of the shipped library
+    static unsigned* dbg = nullptr;
+    const size_t words = static_cast<size_t>(grid) * kG48Waves * 8;
+    if (!dbg) (void)hipMalloc(&dbg, 256 * kG48Waves * 8 * sizeof(unsigned));
+    (void)hipMemsetAsync(dbg, 0, words * sizeof(unsigned), stream);
+    q.dbg = dbg;
+#endif
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(kG48Waves * 64), lds, stream, p, q);
+#ifdef DN_STAMP
+    (void)hipStreamSynchronize(stream);
+    std::vector<unsigned> h(words);
+    (void)hipMemcpy(h.data(), dbg, words * sizeof(unsigned), hipMemcpyDeviceToHost);
+    double acc[2][8] = {};
+    for (size_t w = 0; w < words / 8; ++w)
+      for (int i = 0; i < 8; ++i) acc[(w % kG48Waves) >= 4][i] += h[w * 8 + i];
+    for (int g = 0; g < 2; ++g) {
+      const double n = acc[g][4] > 0 ? acc[g][4] : 1;
+      fprintf(stderr, "[stamp] waves %d-%d: per phase: vmcnt wait %.1f, barrier %.1f, DMA issue %.1f, MFMA segment %.1f = quarters %.1f %.1f %.1f %.1f cycles (%.0f phases)\n",
+              g * 4, g * 4 + 3, acc[g][0] / n, acc[g][1] / n, acc[g][2] / n, acc[g][3] / n, acc[g][5] / n, acc[g][6] / n, acc[g][7] / n,
+              (acc[g][3] - acc[g][5] - acc[g][6] - acc[g][7]) / n, n / (words / 16.0));
+    }
+#endif
     return check_launch("mlp_forward48");
   };
   // fixed-shape instances: the paper network (D8 / W256 / skip 4, view directions - BASELINE configs 2, 4, 5) and the fork's

@@ -47,6 +47,9 @@ struct G48Params {
   const char* base;  // start of the 48-point region of the packed buffer
   int bias_bytes;    // bias rows (padded to 1 KiB); the tables follow, then the pieces
   int total_pieces;
+#ifdef DN_STAMP
+  unsigned* dbg;     // diagnostic build: 8 words per wave
+#endif
 };
 
 

@@ -24,6 +24,7 @@ EXPORTS = (
     "dn_mlp_train_sizes", "dn_mlp_backward_packed_bytes", "dn_mlp_pack_backward", "dn_run_network_train",
     "dn_mlp_backward_data", "dn_mlp_unpack", "dn_mlp_weight_grad", "dn_mlp_weight_grad_all",
     "dn_select_rays", "dn_select_rays_indirect", "dn_ndc_rays", "dn_dex_error_sweep", "dn_depth_error_image",
+    "dn_render_train_workspace_bytes", "dn_render_rays_train", "dn_render_rays_backward",
 )
 
 
@@ -77,9 +78,17 @@ def _declare(lib):
     lib.dn_dex_error_sweep.argtypes = [fp, fp, c_int, c_int64, vp, c_float, c_float, vp, vp]
     lib.dn_depth_error_image.argtypes = [fp, fp, vp, c_int, c_int, c_float, fp, vp]
     lib.dn_mlp_weight_grad_all.argtypes = [POINTER(MlpDesc), c_int, vp, vp, c_int64, POINTER(c_void_p), POINTER(c_void_p), vp]
+    lib.dn_render_train_workspace_bytes.argtypes = [c_int64, c_int, c_int]
+    lib.dn_render_train_workspace_bytes.restype = c_size_t
+    lib.dn_render_rays_train.argtypes = [POINTER(MlpDesc), vp, POINTER(MlpDesc), vp, c_int, fp, c_int, c_int64, c_int, c_int,
+                                         c_int, c_float, c_int, POINTER(c_float), c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp,
+                                         fp, fp, vp, vp, vp, vp, vp, vp]
+    lib.dn_render_rays_backward.argtypes = [POINTER(MlpDesc), vp, POINTER(MlpDesc), vp, c_int, fp, c_int, c_int64, c_int, c_int,
+                                            c_float, c_int, fp, fp, fp, fp, fp, fp, fp, fp, vp, vp, vp, vp, vp, vp, vp,
+                                            POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int, vp]
     for name in EXPORTS:
         if name not in ("dn_last_error", "dn_mlp_packed_bytes", "dn_render_workspace_bytes",
-                        "dn_mlp_backward_packed_bytes"):
+                        "dn_mlp_backward_packed_bytes", "dn_render_train_workspace_bytes"):
             getattr(lib, name).restype = c_int
 
 

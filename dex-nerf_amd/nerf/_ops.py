@@ -398,3 +398,70 @@ def render_rays(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, noise_s
         ptr(rgb_c), ptr(depth_c), ptr(acc_c), ptr(rgb_f), ptr(depth_f), ptr(acc_f), ptr(dex), ptr(ws), stream()),
         "dn_render_rays")
     return rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f, dex
+
+
+# ---- predict_and_render_radiance under autograd: one C call forward, one (or two halves) backward ----------------------
+def render_rays_train(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, noise_std, white, m_thres, draws=None):
+    """dn_render_rays_train: the training forward of a whole ray chunk.  Returns (maps, saved): maps = (rgb_c, depth_c, acc_c,
+    rgb_f, depth_f, acc_f, dex), saved = what dn_render_rays_backward needs (workspace, per-network act / masks, the draws)."""
+    rays = f32c(rays)
+    n = rays.shape[0]
+    dev = rays.device
+    draws = draws or {}
+    k = len(m_thres)
+    fine = num_fine > 0 and packed_f is not None
+    nf = num_fine if fine else 0
+    ws = torch.empty(max(lib().dn_render_train_workspace_bytes(n, num_coarse, nf), 1), dtype=torch.uint8, device=dev)
+
+    def new(*shape):
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+
+    def bufs(packed, n_points):
+        a, m, _ = train_sizes(packed, n_points)
+        return torch.empty(a, dtype=torch.uint8, device=dev), torch.empty(m, dtype=torch.uint8, device=dev)
+    act_c, masks_c = bufs(packed_c, n * num_coarse)
+    act_f, masks_f = bufs(packed_f, n * (num_coarse + nf)) if fine else (None, None)
+    rgb_c, depth_c, acc_c = new(n, 3), new(n), new(n)
+    rgb_f, depth_f, acc_f = (new(n, 3), new(n), new(n)) if fine else (None, None, None)
+    dex = new(k, n) if k else None
+    t = {name: (None if draws.get(name) is None else f32c(draws[name])) for name in ("t_rand", "noise_c", "u", "noise_f")}
+    check(lib().dn_render_rays_train(
+        ctypes.byref(packed_c.desc), ptr(packed_c.buffer),
+        ctypes.byref(packed_f.desc) if fine else None, ptr(packed_f.buffer) if fine else None, packed_c.precision,
+        ptr(rays), rays.shape[1], n, num_coarse, nf, int(bool(lindisp)), float(noise_std), int(bool(white)),
+        host_floats(m_thres), k, ptr(t["t_rand"]), ptr(t["noise_c"]), ptr(t["u"]), ptr(t["noise_f"]),
+        ptr(rgb_c), ptr(depth_c), ptr(acc_c), ptr(rgb_f), ptr(depth_f), ptr(acc_f), ptr(dex), ptr(ws),
+        ptr(act_c), ptr(masks_c), ptr(act_f), ptr(masks_f), stream()), "dn_render_rays_train")
+    saved = dict(rays=rays, ws=ws, act_c=act_c, masks_c=masks_c, act_f=act_f, masks_f=masks_f, noise_c=t["noise_c"],
+                 noise_f=t["noise_f"], n=n, nc=num_coarse, nf=nf, noise_std=float(noise_std), white=bool(white))
+    return (rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f, dex), saved
+
+
+def render_rays_backward(packed_c, packed_f, saved, g_c, g_f, views_c, views_f, nets=3):
+    """dn_render_rays_backward: composite backward -> backward-data chain -> weight gradients for the networks selected by
+    `nets` (bit 0 coarse, bit 1 fine), ACCUMULATING into views_* = [(dW, db)] in linear_modules() order.
+    g_c / g_f = (g_rgb, g_depth, g_acc) upstream gradients (None = zero)."""
+    dev = saved["rays"].device
+    n, nc, nf = saved["n"], saved["nc"], saved["nf"]
+    fine = nf > 0 and packed_f is not None
+
+    def grads_buf(packed, n_points):
+        return torch.empty(train_sizes(packed, n_points)[2], dtype=torch.uint8, device=dev)
+    grads_c = grads_buf(packed_c, n * nc) if nets & 1 else None
+    grads_f = grads_buf(packed_f, n * (nc + nf)) if (fine and nets & 2) else None
+
+    def arrays(views):
+        if views is None:
+            return None, None
+        return ((c_void_p * len(views))(*[w.data_ptr() for w, _ in views]), (c_void_p * len(views))(*[b.data_ptr() for _, b in views]))
+    wc, bc = arrays(views_c if nets & 1 else None)
+    wf, bf = arrays(views_f if (fine and nets & 2) else None)
+    gs = [None if g is None else f32c(g) for g in tuple(g_c) + tuple(g_f)]
+    check(lib().dn_render_rays_backward(
+        ctypes.byref(packed_c.desc), ptr(packed_c.buffer_bwd),
+        ctypes.byref(packed_f.desc) if fine else None, ptr(packed_f.buffer_bwd) if fine else None, packed_c.precision,
+        ptr(saved["rays"]), saved["rays"].shape[1], n, nc, nf, saved["noise_std"], int(saved["white"]),
+        ptr(saved["noise_c"]), ptr(saved["noise_f"]), ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]), ptr(gs[5]),
+        ptr(saved["ws"]), ptr(saved["act_c"]), ptr(saved["masks_c"]), ptr(grads_c), ptr(saved["act_f"]), ptr(saved["masks_f"]),
+        ptr(grads_f), wc, bc, wf, bf, int(nets), stream()), "dn_render_rays_backward")
+    return grads_c, grads_f   # (kept alive by the caller until the stream has consumed them: PyTorch's caching allocator is stream-ordered)

@@ -141,6 +141,86 @@ class FusedNetFn(torch.autograd.Function):
         return (None, None, None, None, None, None) + tuple(flat)
 
 
+class RenderRaysTrainFn(torch.autograd.Function):
+    """predict_and_render_radiance for one ray chunk in train mode (reference nerf/train_utils.py:92-202), differentiable
+    w.r.t. the parameters of both networks: ONE C-ABI call forward (dn_render_rays_train) and one backward
+    (dn_render_rays_backward) - or its two halves, fine network first, when a FlatGradBucket wants to start the fine network's
+    all-reduce while the coarse half runs.  Same kernels, same order, same bits as the stage-by-stage composition."""
+
+    @staticmethod
+    def forward(ctx, model_c, model_f, rays, cfg, draws, thres, logs, *params):
+        num_coarse, num_fine, lindisp, noise_std, white = cfg
+        pc = model_c.packed(*logs)
+        pf = model_f.packed(*logs) if model_f is not None else None
+        for model, pk in ((model_c, pc), (model_f, pf)):
+            if model is None:
+                continue
+            key = model.param_key()
+            if pk.key_bwd != key or torch.cuda.is_current_stream_capturing():
+                _ops.pack_backward(pk, [m.weight for m in model.linear_modules()])
+                pk.key_bwd = key
+        maps, saved = _ops.render_rays_train(pc, pf, rays, num_coarse, num_fine, lindisp, noise_std, white, thres, draws)
+        ctx.models, ctx.packed, ctx.saved = (model_c, model_f), (pc, pf), saved
+        ctx.sinks = tuple(getattr(m, "_grad_sink", None) if m is not None else None for m in (model_c, model_f))
+        for sink in ctx.sinks:
+            if sink is not None:
+                sink.forward_issued()
+        ctx.set_materialize_grads(False)
+        dex = maps[6]
+        if dex is not None:
+            ctx.mark_non_differentiable(dex)
+        return maps
+
+    @staticmethod
+    def backward(ctx, g_rgb_c, g_depth_c, g_acc_c, g_rgb_f, g_depth_f, g_acc_f, _g_dex=None):
+        model_c, model_f = ctx.models
+        pc, pf = ctx.packed
+        saved = ctx.saved
+        fine = model_f is not None and saved["nf"] > 0
+        g_c, g_f = (g_rgb_c, g_depth_c, g_acc_c), (g_rgb_f, g_depth_f, g_acc_f)
+        sink_c, sink_f = ctx.sinks
+        views_c = sink_c.views(model_c) if sink_c is not None else None
+        views_f = sink_f.views(model_f) if (fine and sink_f is not None) else None
+        n_c = 2 * len(model_c.linear_modules())
+        n_f = 2 * len(model_f.linear_modules()) if model_f is not None else 0
+        if views_c is not None and (views_f is not None or not fine):
+            # gradients accumulate straight into the bucket's views; the fine half first so that its exchange is in flight
+            # while the coarse half runs
+            keep = []
+            if fine:
+                keep.append(_ops.render_rays_backward(pc, pf, saved, g_c, g_f, views_c, views_f, nets=2))
+                sink_f.backward_done()
+            keep.append(_ops.render_rays_backward(pc, pf, saved, g_c, g_f, views_c, views_f, nets=1))
+            sink_c.backward_done()
+            return (None,) * (7 + n_c + n_f)
+
+        def fresh(model):
+            shapes = [tuple(m.weight.shape) for m in model.linear_modules()]
+            flat = torch.zeros(sum(o * i + o for o, i in shapes), dtype=torch.float32, device=saved["rays"].device)
+            out, off = [], 0
+            for o, i in shapes:
+                out.append((flat[off:off + o * i].view(o, i), flat[off + o * i:off + o * i + o]))
+                off += o * i + o
+            return out
+        views_c = fresh(model_c)
+        views_f = fresh(model_f) if fine else None
+        _ops.render_rays_backward(pc, pf, saved, g_c, g_f, views_c, views_f, nets=3)
+        grads = [t for pair in views_c for t in pair]
+        if model_f is not None:
+            grads += [t for pair in views_f for t in pair] if fine else [None] * n_f
+        return (None,) * 7 + tuple(grads)
+
+
+def render_rays_train(model_c, model_f, rays, cfg, draws, thres, logs):
+    """The fused training path of predict_and_render_radiance (both networks covered by the training kernels)."""
+    params = []
+    for model in (model_c, model_f):
+        if model is not None:
+            for m in model.linear_modules():
+                params += [m.weight, m.bias]
+    return RenderRaysTrainFn.apply(model_c, model_f, rays, cfg, draws, thres, logs, *params)
+
+
 def mlp_encoded(model, x):
     """FlexibleNeRFModel.forward(x) on already-embedded device rows."""
     if needs_grad(model, x):

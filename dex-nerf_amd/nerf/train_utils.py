@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from . import _ops
-from ._train import needs_grad, run_network_fused, run_network_fused_rays, train_fused_ok
+from ._train import inputs_need_grad, needs_grad, render_rays_train, run_network_fused, run_network_fused_rays, train_fused_ok
 from .models import FlexibleNeRFModel
 from .nerf_helpers import Embedder, _require_device, get_minibatches, ndc_rays
 from .nerf_helpers import sample_pdf_2 as sample_pdf  # noqa: F401  (reference train_utils.py:6 alias)
@@ -87,6 +87,10 @@ def depth_error_img(D_est_tensor, D_gt_tensor, mask, abs_thres=1., dilate_radius
 
 
 # ---- hot path ------------------------------------------------------------------------------------------
+import os as _os
+_STAGEWISE_TRAINING = [bool(int(_os.environ.get("DEXNERF_STAGEWISE_TRAINING", "0")))]   # tests flip this to compare the two routes
+
+
 def _fusable(network_fn, embed_fn, embeddirs_fn):
     if not (isinstance(network_fn, FlexibleNeRFModel) and network_fn.fused_ok()):
         return False
@@ -184,7 +188,28 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mo
         dex_list = [] if dex is None else [dex[k] for k in range(dex.shape[0])]
         return tuple([rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f] + dex_list)
 
-    # stage-by-stage composition (training / autograd, or a network the fused kernel does not cover)
+    if (fused_models and train_fused_ok(model_coarse) and (not fine or train_fused_ok(model_fine))
+            and not inputs_need_grad(ray_batch) and not _STAGEWISE_TRAINING[0]):
+        # training: the whole chunk as one differentiable op - one C-ABI call forward (dn_render_rays_train), one backward
+        # (dn_render_rays_backward); draws in the reference's order
+        draws = {}
+        if perturb:
+            draws["t_rand"] = rand(n, nc)
+        if std > 0.0:
+            draws["noise_c"] = randn(n, nc)
+        if fine and perturb:
+            draws["u"] = rand(n, nf)
+        if fine and std > 0.0:
+            draws["noise_f"] = randn(n, nc + nf)
+        logs = (encode_position_fn.log_sampling, encode_direction_fn.log_sampling if use_viewdirs else True)
+        rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f, dex = render_rays_train(
+            model_coarse, model_fine if fine else None, _ops.f32c(ray_batch), (nc, nf if fine else 0, lindisp, std, white), draws,
+            thres, logs)
+        dex_list = [] if dex is None else [dex[k] for k in range(dex.shape[0])]
+        return tuple([rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f] + dex_list)
+
+    # stage-by-stage composition (autograd through a network the fused training kernels do not cover, inputs that
+    # require grad, or DEXNERF_STAGEWISE_TRAINING=1)
     rays = _ops.f32c(ray_batch)
     ro, rd = rays[..., :3], rays[..., 3:6]
     z_vals = _ops.coarse_depths(rays, nc, lindisp, rand(n, nc) if perturb else None)

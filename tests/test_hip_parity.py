@@ -1209,3 +1209,64 @@ def test_config4_full_size_render_properties_bf16(dev):
     frac, worst = dex_agreement(np.stack([C(o.reshape(-1)[sel]) for o in a[6:]]), np.stack([o.numpy() for o in ref[6:]]))
     print(f"800x800 64+192 bf16: rgb PSNR {psnr:.1f} dB vs the fp32 oracle on 512 rays; Dex agreement {frac:.4f}, worst miss {worst:.3f} m")
     assert psnr > 38.0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_one_call_training_path_equals_stage_composition(golden, dev, precision, monkeypatch):
+    """predict_and_render_radiance under autograd as ONE C-ABI call forward
+    (dn_render_rays_train) and one backward (dn_render_rays_backward), against the stage-by-stage Python composition of the
+    same kernels (coarse depths -> FusedNetFn -> VolumeRenderFn -> fine depths -> FusedNetFn -> VolumeRenderFn) on the
+    reference's recorded training rays and RNG draws: the six maps, the Dex depths and every saved-gradient-independent
+    quantity are bit-identical; the parameter gradients agree to the reordering noise of the weight-gradient kernel's fp32
+    atomics (its partial sums arrive in a different order from launch to launch).  Also with a FlatGradBucket attached:
+    the two half-calls (fine, then coarse) accumulate straight into the bucket and autograd hands back no gradient."""
+    import nerf
+    from nerf import parallel, train_utils
+    name = "train_d8w256"
+    g = golden(name)
+    mkw, wfn, rkw = CASES[name]
+    cfg = make_cfg(rkw)
+    draws = draws_of(g)
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    target = G(g["target"], dev)
+
+    def run(stagewise, bucket=False):
+        mc, mf = make_models(mkw, *wfn(), dev)
+        b = parallel.FlatGradBucket([mc, mf]) if bucket else None
+        q_rand = [G(draws["t_rand"], dev), G(draws["u"], dev)]
+        q_randn = [G(draws["noise_c"], dev), G(draws["noise_f"], dev)]
+        monkeypatch.setattr(torch, "rand", lambda *a, **k: q_rand.pop(0))
+        monkeypatch.setattr(torch, "randn", lambda *a, **k: q_randn.pop(0))
+        monkeypatch.setattr(train_utils, "_STAGEWISE_TRAINING", [stagewise])
+        out = nerf.run_one_iter_of_nerf(1, len(g["ro"]), 1.0, mc, mf, G(g["ro"], dev), G(g["rd"], dev), cfg, mode="train",
+                                        encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=list(M_THRES))
+        assert not q_rand and not q_randn
+        # a loss that also pulls on depth and acc, so all six upstream gradients are exercised
+        loss = (nerf.img2mse(out[0], target) + nerf.img2mse(out[3], target) + 0.1 * out[1].mean() + 0.05 * out[2].mean()
+                + 0.1 * out[4].mean() + 0.05 * out[5].mean())
+        if b is not None:
+            b.zero()
+        loss.backward()
+        grads = {("c" if m is mc else "f") + "." + k: p.grad.detach().clone() for m in (mc, mf) for k, p in m.named_parameters()}
+        return [o.detach() for o in out], grads, b
+
+    nerf.set_precision(precision)
+    try:
+        calls = []
+        orig = nerf._train.RenderRaysTrainFn.apply
+        monkeypatch.setattr(nerf._train.RenderRaysTrainFn, "apply", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        out_s, grads_s, _ = run(True)
+        assert not calls
+        out_1, grads_1, _ = run(False)
+        assert len(calls) == 1
+        out_b, grads_b, bucket = run(False, bucket=True)
+    finally:
+        nerf.set_precision("fp32")
+    for a, b, c in zip(out_s, out_1, out_b):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    for k in grads_s:
+        scale = float(grads_s[k].abs().max()) + 1e-30
+        assert float((grads_s[k] - grads_1[k]).abs().max()) <= 2e-5 * scale, k
+        assert float((grads_s[k] - grads_b[k]).abs().max()) <= 2e-5 * scale, k
+    lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + 4 * bucket.flat.numel()
+    assert all(lo <= p.grad.data_ptr() < hi for p in bucket.params)

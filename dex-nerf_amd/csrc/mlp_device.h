@@ -133,6 +133,14 @@ struct Pipe {
 #ifdef DN_STAMP   // diagnostic build only: where a wave's cycles go at the phase boundaries (s_memtime, accumulated in SGPRs)
   unsigned st_vm = 0, st_bar = 0, st_dma = 0, st_seg = 0, st_n = 0, st_prev = 0;
   unsigned st_sub[4] = {0, 0, 0, 0}, st_last = 0;   // MFMA time of the four quarters of a phase (4 pieces each)
+  unsigned st_top = 0, st_top_pending = 0;          // end of a pass (tail pieces, output store, next tile's encodings) up to the next phase
+  __device__ __forceinline__ void pass_end() {       // after the last full quarter of a pass
+    const unsigned t = stamp();
+    if (st_n) st_tail += t - st_last;     // light mode: st_tail = the whole pass minus its top
+    st_last = t;
+    st_top_pending = 1;
+  }
+  unsigned st_tail = 0;
   template <int I>
   __device__ __forceinline__ void substamp() {       // at piece 4 * I of a phase, I = 1..3
     const unsigned t = stamp();
@@ -212,8 +220,14 @@ struct Pipe {
 #else
     const unsigned who = wave;
 #endif
+#ifdef DN_PIPE_LEADER_DMA
+    // waves 0-3 fetch the whole phase, four pieces each (two right after the barrier, two at mid-phase); waves 4-7 none
+    pend_src = q_issue + who * (2 * PER_WAVE * kPieceBytes);
+    pend_dst = slot_wr * kSlotBytes + who * (2 * PER_WAVE * kPieceBytes);
+#else
     pend_src = q_issue + who * (PER_WAVE * kPieceBytes);
     pend_dst = slot_wr * kSlotBytes + who * (PER_WAVE * kPieceBytes);
+#endif
     q_issue += kSlotBytes;
     if (q_issue >= total_bytes) q_issue = 0;
     slot_wr = (slot_wr + 1 == kRingPhases) ? 0 : slot_wr + 1;
@@ -227,7 +241,12 @@ struct Pipe {
 
   __device__ __forceinline__ void issue_phase() {  // prologue only
     advance_issue();
+#ifdef DN_PIPE_LEADER_DMA
+    dma_phase(pend_src, pend_dst, wave < 4 ? 1u : 0u);
+    dma_phase(pend_src + PER_WAVE * kPieceBytes, pend_dst + PER_WAVE * kPieceBytes, wave < 4 ? 1u : 0u);
+#else
     dma_phase(pend_src, pend_dst, 1u);
+#endif
   }
 
   // Called at every 16-piece boundary of the (compile-time laid out) consumption sequence.
@@ -253,12 +272,24 @@ struct Pipe {
     // No LDS wait here: every read of the slot being recycled (phase p-1) was waited for by the take() in front of its
     // MFMAs, which precede this point in program order; the reads still in flight belong to phases p and p+1.
     static_assert(PER_WAVE == 2, "the asm-read pipeline is the 8-wave geometry");
-#ifdef DN_STAMP
-    const unsigned st0 = stamp();
-    if (st_n) { st_seg += st0 - st_prev; st_sub[3] += st0 - st_last; }
+#ifdef DN_PIPE_LEADER_DMA
+#define DN_PHASE_VMCNT "8"   // a fetching wave has four DMAs per phase: two younger phases stay in flight
+#else
+#define DN_PHASE_VMCNT "4"
 #endif
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#ifdef DN_STAMP
+#if defined(DN_STAMP) && DN_STAMP == 2   // light mode: only the top-of-tile time (two stamps per pass)
+    if (st_top_pending) { st_top += stamp() - st_last; st_top_pending = 0; ++st_n; }
+#elif defined(DN_STAMP) && DN_STAMP == 3   // barrier mode: arrival / release of every phase barrier (two stamps per phase)
+    const unsigned st0 = stamp();
+    if (st_top_pending) { st_top += st0 - st_last; st_top_pending = 0; }
+    else if (st_n) st_seg += st0 - st_prev;
+#elif defined(DN_STAMP)
+    const unsigned st0 = stamp();
+    if (st_top_pending) { st_top += st0 - st_last; st_top_pending = 0; }
+    else if (st_n) { st_seg += st0 - st_prev; st_sub[3] += st0 - st_last; }
+#endif
+    asm volatile("s_waitcnt vmcnt(" DN_PHASE_VMCNT ")" ::: "memory");
+#if defined(DN_STAMP) && DN_STAMP == 1
     const unsigned st1 = stamp();
     st_vm += st1 - st0;
 #endif
@@ -285,13 +316,21 @@ struct Pipe {
 #ifndef DN_EXP_NOBARRIER   // timing experiment only (UNSAFE: no cross-wave ordering of ring slots)
     __builtin_amdgcn_s_barrier();
 #endif
-#if defined(DN_STAMP) && defined(DN_PIPE_ASM_READS)
+#if defined(DN_STAMP) && DN_STAMP == 1 && defined(DN_PIPE_ASM_READS)
     const unsigned st2 = stamp();
     st_bar += st2 - st1;
+#elif defined(DN_STAMP) && DN_STAMP == 3
+    st_prev = stamp();
+    st_bar += st_prev - st0;
+    st_last = st_prev;
+    ++st_n;
+#endif
+#if defined(DN_G48_PRIO) && DN_G48_PRIO == 2   // first half of a phase: the younger waves (4-7) lead, second half: the older ones
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
     advance_issue();
     dma_phase(pend_src, pend_dst, (WAVES == 4 || wave < 4) ? 1u : 0u);
-#if defined(DN_STAMP) && defined(DN_PIPE_ASM_READS)
+#if defined(DN_STAMP) && DN_STAMP == 1 && defined(DN_PIPE_ASM_READS)
     st_prev = stamp();
     st_dma += st_prev - st2;
     st_last = st_prev;
@@ -309,12 +348,19 @@ struct Pipe {
   }
 
   __device__ __forceinline__ void mid_phase() {
+#if defined(DN_G48_PRIO) && DN_G48_PRIO == 2
+    if (wave >= 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
+#endif
 #ifndef DN_EXP_REGSTAGE
-#ifdef DN_STAMP
+#if defined(DN_STAMP) && DN_STAMP == 1
     const unsigned m0 = stamp();
 #endif
+#ifdef DN_PIPE_LEADER_DMA
+    if constexpr (WAVES == 8) dma_phase(pend_src + PER_WAVE * kPieceBytes, pend_dst + PER_WAVE * kPieceBytes, wave < 4 ? 1u : 0u);
+#else
     if constexpr (WAVES == 8) dma_phase(pend_src, pend_dst, wave >= 4 ? 1u : 0u);
-#ifdef DN_STAMP
+#endif
+#if defined(DN_STAMP) && DN_STAMP == 1
     const unsigned m1 = stamp();
     st_dma += m1 - m0;
     st_prev += m1 - m0;   // keep the DMA issue out of the MFMA-segment figure
@@ -350,7 +396,11 @@ struct Pipe {
     constexpr int q = (POS % kPhasePieces) + kPrefetch;
 #ifdef DN_PIPE_ASM_READS
     const unsigned base = (q < kPhasePieces) ? rda_cur : slot_cur_base + lane16;
+#ifdef DN_EXP_NOREAD   // timing experiment only: no A-fragment traffic (the FIFO keeps whatever it held)
+    asm volatile("; no read %1" : "+v"(af[POS % kPrefetch]) : "v"(base));
+#else
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[POS % kPrefetch]) : "v"(base), "n"((q % kPhasePieces) * kPieceBytes));
+#endif
 #else
     const char* base = (q < kPhasePieces) ? rd_cur : rd_nxt;
 #ifndef DN_EXP_NOREAD

@@ -15,6 +15,14 @@
 #ifndef DN_G48_COMPILER_READS    // (ablation hook: the r01 pipeline with compiler-issued reads and waits)
 #define DN_PIPE_ASM_READS 1      // A-fragment / bias LDS reads and their counted waits as opaque asm (mlp_device.h Pipe)
 #endif
+#ifndef DN_G48_SYMMETRIC_DMA     // (ablation hook: every wave fetches two pieces per phase, as in round 1)
+// Asymmetric roles.  The two waves of a SIMD do not share the matrix pipe fairly: the older one (waves 0-3) wins the
+// arbitration, runs a phase ahead and then sits at the phase barrier (s_memtime stamps, profiles/r02_fine_net_stalls.md:
+// ~640 cycles per phase against ~160 for waves 4-7), while the younger one - the critical path - also paid ~300 cycles per
+// phase of its own LDS-DMA issue.  So the waves with the slack fetch the whole weight stream (four pieces each) and
+// waves 4-7 issue MFMAs only.
+#define DN_PIPE_LEADER_DMA 1
+#endif
 #include <vector>
 
 #include "mlp_geo48.h"
@@ -54,7 +62,7 @@ __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, 
     static_for<KT>([&](auto k_c) {
       constexpr int k = decltype(k_c)::value;
       constexpr int pos = POS0 + nt * KT + k;
-#ifdef DN_STAMP
+#if defined(DN_STAMP) && DN_STAMP == 1
       if constexpr (pos % 4 == 0 && pos % kPhasePieces != 0) pipe.template substamp<(pos % kPhasePieces) / 4>();
 #endif
       if constexpr (pos % kPhasePieces == 0) pipe.phase_begin();
@@ -262,6 +270,9 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
   for (int e = 0; e < kPrefetch; ++e) pipe.af[e] = *reinterpret_cast<const f32x4*>(pipe.rd_nxt + e * kPieceBytes);
 #endif
 
+#if defined(DN_G48_PRIO) && DN_G48_PRIO == 1   // static priority for the younger half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   int vset = 0;  // which view-direction rows hold this tile's directions (wave-uniform, flips every tile)
   const int n_tiles = static_cast<int>(p.n_tiles);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, vset ^= 1) {
@@ -271,6 +282,11 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       const int j = ln & 15;
       const f32x4* tabx = reinterpret_cast<const f32x4*>(tab_lds) + (ln >> 4) * 16;
       char* pex = pex_of(ln);
+#ifdef DN_PIPE_LEADER_DMA
+      // waves 4-7 issue no weight DMAs, so no counted wait of theirs ever pushes this tile's input DMAs (issued one tile
+      // ago) through: they wait for them here - by now their VMEM queue holds nothing else but the last output stores
+      if (wave >= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       float in[PT][7];
 #pragma unroll
       for (int t = 0; t < PT; ++t)
@@ -412,6 +428,9 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       if (p.use_viewdirs) heads(ba, bb, std::true_type{});
       else heads(ba, bb, std::false_type{});
     }
+#ifdef DN_STAMP
+    pipe.pass_end();
+#endif
     const int lo = fresh_lane();
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
@@ -426,9 +445,10 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifdef DN_STAMP
   if ((threadIdx.x & 63) == 0) {
-    unsigned* d = q.dbg + (blockIdx.x * WAVES + wave) * 8;
+    unsigned* d = q.dbg + (blockIdx.x * WAVES + wave) * 16;
     d[0] = pipe.st_vm; d[1] = pipe.st_bar; d[2] = pipe.st_dma; d[3] = pipe.st_seg; d[4] = pipe.st_n;
-    d[5] = pipe.st_sub[0]; d[6] = pipe.st_sub[1]; d[7] = pipe.st_sub[2];
+    d[5] = pipe.st_sub[0]; d[6] = pipe.st_sub[1]; d[7] = pipe.st_sub[2]; d[3] = pipe.st_sub[3];
+    d[8] = pipe.st_top; d[9] = pipe.st_tail;
   }
 #endif
 }
@@ -541,8 +561,8 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
     if (int rc = ensure_big_lds(reinterpret_cast<const void*>(kern))) return rc;
 #ifdef DN_STAMP   // diagnostic build: synchronous, allocates, prints - never part of the shipped library
     static unsigned* dbg = nullptr;
-    const size_t words = static_cast<size_t>(grid) * kG48Waves * 8;
-    if (!dbg) (void)hipMalloc(&dbg, 256 * kG48Waves * 8 * sizeof(unsigned));
+    const size_t words = static_cast<size_t>(grid) * kG48Waves * 16;
+    if (!dbg) (void)hipMalloc(&dbg, 256 * kG48Waves * 16 * sizeof(unsigned));
     (void)hipMemsetAsync(dbg, 0, words * sizeof(unsigned), stream);
     q.dbg = dbg;
 #endif
@@ -551,14 +571,24 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
     (void)hipStreamSynchronize(stream);
     std::vector<unsigned> h(words);
     (void)hipMemcpy(h.data(), dbg, words * sizeof(unsigned), hipMemcpyDeviceToHost);
-    double acc[2][8] = {};
-    for (size_t w = 0; w < words / 8; ++w)
-      for (int i = 0; i < 8; ++i) acc[(w % kG48Waves) >= 4][i] += h[w * 8 + i];
-    for (int g = 0; g < 2; ++g) {
+    double acc[2][16] = {};
+    for (size_t w = 0; w < words / 16; ++w)
+      for (int i = 0; i < 16; ++i) acc[(w % kG48Waves) >= 4][i] += h[w * 16 + i];
+#if DN_STAMP == 2
+    for (int g = 0; g < 2; ++g)
+      fprintf(stderr, "[stamp] waves %d-%d: per pass: top-of-tile %.0f cycles, rest of the pass %.0f (%.1f passes per wave)\n", g * 4, g * 4 + 3,
+              acc[g][8] / acc[g][4], acc[g][9] / acc[g][4], acc[g][4] / (words / 32.0));
+#endif
+#if DN_STAMP == 3
+    for (int g = 0; g < 2; ++g)
+      fprintf(stderr, "[stamp] waves %d-%d: per phase: release -> next arrival %.1f, barrier (arrival -> release, incl. the vmcnt wait) %.1f cycles; per pass: top-of-tile %.0f\n",
+              g * 4, g * 4 + 3, acc[g][3] / acc[g][4], acc[g][1] / acc[g][4], acc[g][8] / (acc[g][4] / 74.0));
+#endif
+    for (int g = 0; g < 2 && DN_STAMP == 1; ++g) {
       const double n = acc[g][4] > 0 ? acc[g][4] : 1;
-      fprintf(stderr, "[stamp] waves %d-%d: per phase: vmcnt wait %.1f, barrier %.1f, DMA issue %.1f, MFMA segment %.1f = quarters %.1f %.1f %.1f %.1f cycles (%.0f phases)\n",
-              g * 4, g * 4 + 3, acc[g][0] / n, acc[g][1] / n, acc[g][2] / n, acc[g][3] / n, acc[g][5] / n, acc[g][6] / n, acc[g][7] / n,
-              (acc[g][3] - acc[g][5] - acc[g][6] - acc[g][7]) / n, n / (words / 16.0));
+      fprintf(stderr, "[stamp] waves %d-%d: per phase: vmcnt wait %.1f, barrier %.1f, DMA issue %.1f, quarters %.1f %.1f %.1f %.1f cycles (%.0f phases per wave); per PASS: tail %.0f, top-of-tile %.0f\n",
+              g * 4, g * 4 + 3, acc[g][0] / n, acc[g][1] / n, acc[g][2] / n, acc[g][5] / n, acc[g][6] / n, acc[g][7] / n, acc[g][3] / n,
+              n / (words / 32.0), acc[g][9] / (n / 74.0), acc[g][8] / (n / 74.0));
     }
 #endif
     return check_launch("mlp_forward48");

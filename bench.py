@@ -363,11 +363,16 @@ def main():
                 torch.cuda.synchronize()
                 dt32 = (time.perf_counter() - t1) / 3
                 kt32, ktf32 = time_dominant_kernel(models, ro, rd, "fp32", reps=2)
-                rgb32 = out32[3].reshape(-1, 3)[torch.from_numpy(sel).to(dev)].cpu().numpy()
-                err32 = float(np.abs(rgb32 - ref[3].numpy()).max() / np.abs(ref[3].numpy()).max())
+                rgb32 = out32[3].reshape(-1, 3)[torch.from_numpy(sel).to(dev)].cpu().numpy().astype(np.float64)
+                per_ray = np.abs(rgb32 - ref[3].numpy()).max(-1) / np.abs(ref[3].numpy()).max()
+                # max over 16,384 rays sits on a handful of rays where an ulp in sigma moves a resampled depth: two fp32-level
+                # evaluations of the reference itself differ by 6.0e-4 there (3 rays over 1e-4, p99.9 9.4e-6:
+                # profiles/r02_fp32_noise_floor.md); the 1e-4 gate of the parity tests is on the golden rays
                 result["fp32_mode"] = {"value": H * W / dt32, "unit": "rays/s", "kernel_ms": kt32 * 1e3, "tflops": ktf32,
                                        "peak": PEAK_TFLOPS["fp32"], "frac": ktf32 / PEAK_TFLOPS["fp32"],
-                                       "rgb_fine_rel_err_vs_oracle": err32, "dex_vs_oracle": dex_agreement(out32, ref, sel, dev)}
+                                       "rgb_fine_rel_err_vs_oracle": {"max": float(per_ray.max()), "p99_9": float(np.quantile(per_ray, 0.999)),
+                                                                      "rays_over_1e-4": int((per_ray > 1e-4).sum()), "rays": int(per_ray.size)},
+                                       "dex_vs_oracle": dex_agreement(out32, ref, sel, dev)}
             finally:
                 nerf.set_precision(args.precision)
         if not args.no_train and world == 1:

@@ -141,6 +141,13 @@ struct Pipe {
     st_top_pending = 1;
   }
   unsigned st_tail = 0;
+  unsigned st_cls[3] = {0, 0, 0};                    // DN_STAMP == 4: time per stage class (layer1 / trunk / heads)
+  template <int CLS>
+  __device__ __forceinline__ void stage_end() {
+    const unsigned t = stamp();
+    st_cls[CLS] += t - st_last;
+    st_last = t;
+  }
   template <int I>
   __device__ __forceinline__ void substamp() {       // at piece 4 * I of a phase, I = 1..3
     const unsigned t = stamp();
@@ -279,6 +286,8 @@ struct Pipe {
 #endif
 #if defined(DN_STAMP) && DN_STAMP == 2   // light mode: only the top-of-tile time (two stamps per pass)
     if (st_top_pending) { st_top += stamp() - st_last; st_top_pending = 0; ++st_n; }
+#elif defined(DN_STAMP) && DN_STAMP == 4   // stage mode: the top-of-tile ends at the first phase boundary of a pass
+    if (st_top_pending) { const unsigned t = stamp(); st_top += t - st_last; st_last = t; st_top_pending = 0; ++st_n; }
 #elif defined(DN_STAMP) && DN_STAMP == 3   // barrier mode: arrival / release of every phase barrier (two stamps per phase)
     const unsigned st0 = stamp();
     if (st_top_pending) { st_top += st0 - st_last; st_top_pending = 0; }

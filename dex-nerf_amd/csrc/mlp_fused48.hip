@@ -321,10 +321,23 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     BP8 none[PT][1];
     int bias_tile = 0;
     // ---- layer1: xyz encoding -> W, no activation (models.py:238) ----
-    run_stage48<F, NT, 0, KXP, 0, false, ST>(pipe, none, pe_xyz, bias_at(0), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
-      emit48<F, false, decltype(nt_c)::value>(acc, ba[decltype(t_c)::value]);
-    });
+    // (the encoding pieces go into registers once per stage - bb is still free here: read through the pe_xyz lambda they
+    // are re-read from LDS for every tile, because the DMA asm's memory clobber forbids the compiler to keep them, each time
+    // behind a compiler-placed lgkmcnt(0): layer1 took 14 k cycles per pass for 3 k cycles of MFMA work)
+    {
+      BP8 pe[PT][KXP];
+#pragma unroll
+      for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int k = 0; k < KXP; ++k) pe[t][k] = pe_xyz(t, k);
+      run_stage48<F, NT, KXP, 0, 0, false, ST>(pipe, pe, no_pe, bias_at(0), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
+        emit48<F, false, decltype(nt_c)::value>(acc, ba[decltype(t_c)::value]);
+      });
+    }
     bias_tile += NT;
+#if defined(DN_STAMP) && DN_STAMP == 4
+    pipe.template stage_end<0>();
+#endif
     float out4[PT][4];
     // ---- heads on the trunk output hx (hy: the other, by then free, activation set) ----
     auto heads = [&](const BP8 (&hx)[PT][KH], BP8 (&hy)[PT][KH], auto view_c) __attribute__((always_inline)) {
@@ -365,7 +378,10 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         // ---- layers_dir[0] on cat(feat, view) -> W/2, ReLU (models.py:250-252) ----
         constexpr int POS_D = ((NT + 1) * KH) % kPhasePieces;
         BP8 bg[PT][KH / 2];
-        auto pe_dir = [&](int t, int) { return *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes); };
+        BP8 ped[PT];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) ped[t] = *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes);
+        auto pe_dir = [&](int t, int) { return ped[t]; };
         run_stage48<F, NT / 2, KH, KDP, POS_D, false, ST>(pipe, hy, pe_dir, bias_at(bias_tile), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
           emit48<F, true, decltype(nt_c)::value>(acc, bg[decltype(t_c)::value]);
         });
@@ -397,10 +413,25 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         auto& bin = (i % 2 == 0) ? ba : bb;
         auto& bout = (i % 2 == 0) ? bb : ba;
         auto emit = [&](auto nt_c, auto t_c, const f32x4& acc) { emit48<F, true, decltype(nt_c)::value>(acc, bout[decltype(t_c)::value]); };
-        if constexpr ((MASKC >> i) & 1u) run_stage48<F, NT, KH, KXP, 0, false, false>(pipe, bin, pe_xyz, bias_at(bias_tile), 0u, emit);
-        else run_stage48<F, NT, KH, 0, 0, false, false>(pipe, bin, no_pe, bias_at(bias_tile), 0u, emit);
+        if constexpr ((MASKC >> i) & 1u) {
+#ifdef DN_G48_SKIP_PE_FROM_LDS
+          run_stage48<F, NT, KH, KXP, 0, false, false>(pipe, bin, pe_xyz, bias_at(bias_tile), 0u, emit);
+#else
+          BP8 pe[PT][KXP];   // the skip layer's second K panel, in registers for the stage (see layer1)
+#pragma unroll
+          for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int k = 0; k < KXP; ++k) pe[t][k] = pe_xyz(t, k);
+          run_stage48<F, NT, KH, KXP, 0, false, false>(pipe, bin, [&](int t, int k) { return pe[t][k]; }, bias_at(bias_tile), 0u, emit);
+#endif
+        } else {
+          run_stage48<F, NT, KH, 0, 0, false, false>(pipe, bin, no_pe, bias_at(bias_tile), 0u, emit);
+        }
         bias_tile += NT;
       });
+#if defined(DN_STAMP) && DN_STAMP == 4
+      pipe.template stage_end<1>();
+#endif
       if constexpr ((DC - 1) % 2 == 0) heads(ba, bb, std::integral_constant<bool, VIEWC != 0>{});
       else heads(bb, ba, std::integral_constant<bool, VIEWC != 0>{});
     } else {
@@ -448,7 +479,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     unsigned* d = q.dbg + (blockIdx.x * WAVES + wave) * 16;
     d[0] = pipe.st_vm; d[1] = pipe.st_bar; d[2] = pipe.st_dma; d[3] = pipe.st_seg; d[4] = pipe.st_n;
     d[5] = pipe.st_sub[0]; d[6] = pipe.st_sub[1]; d[7] = pipe.st_sub[2]; d[3] = pipe.st_sub[3];
-    d[8] = pipe.st_top; d[9] = pipe.st_tail;
+    d[8] = pipe.st_top; d[9] = pipe.st_tail; d[10] = pipe.st_cls[0]; d[11] = pipe.st_cls[1];
   }
 #endif
 }
@@ -578,6 +609,11 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
     for (int g = 0; g < 2; ++g)
       fprintf(stderr, "[stamp] waves %d-%d: per pass: top-of-tile %.0f cycles, rest of the pass %.0f (%.1f passes per wave)\n", g * 4, g * 4 + 3,
               acc[g][8] / acc[g][4], acc[g][9] / acc[g][4], acc[g][4] / (words / 32.0));
+#endif
+#if DN_STAMP == 4
+    for (int g = 0; g < 2; ++g)
+      fprintf(stderr, "[stamp] waves %d-%d: per pass: top %.0f, layer1 (32 pieces, 16 tiles) %.0f, trunk (928 pieces, 112 tiles) %.0f, heads (212 pieces + 12 pad, 26 tiles) %.0f cycles\n",
+              g * 4, g * 4 + 3, acc[g][8] / acc[g][4], acc[g][10] / acc[g][4], acc[g][11] / acc[g][4], acc[g][9] / acc[g][4]);
 #endif
 #if DN_STAMP == 3
     for (int g = 0; g < 2; ++g)

@@ -8,7 +8,9 @@ for depth); neither package is in this image, so the two resamplers are restated
   * INTER_NEAREST = source index floor(dst * scale).
 Parity status: pose_spherical is pinned to a golden captured from the reference; the loaders are checked against
 hand-built scenes (tests/test_host_side.py) but NOT against the reference's own loaders, which cannot run here
-(cv2 / imageio absent) - "parity unpinned" for the resampling arithmetic (expected: equal up to fp32 summation order).
+(cv2 / imageio absent) - "parity unpinned" for the resampling arithmetic.  The integer-factor INTER_AREA path follows OpenCV's
+documented float rule in its own summation order (tests/test_datasets.py checks a hand-computed 4x4 -> 2x2 case whose fp32 result
+depends on that order); it stays unpinned until fixtures produced by the reference's loaders exist.
 """
 import json
 import os
@@ -62,9 +64,18 @@ def resize_area(img, height, width):
     img = np.asarray(img, np.float32)
     h, w = img.shape[:2]
     if h % height == 0 and w % width == 0:
+        # integer factors - the only case the reference's non-debug paths use (load_messytable.py:148-157: /2,
+        # load_blender.py:107-119: /4), on float32 images already divided by 255 (:83 / :66).  OpenCV's area-fast path for
+        # float data: the fy x fx block summed sequentially in float (rows outer, columns inner), times the float scale
+        # 1 / (fx * fy) - restated in that order so that fp32 rounding follows it too (no uint8 rounding is involved:
+        # saturate_cast<float> is the identity).
         fy, fx = h // height, w // width
         blocks = img.reshape((height, fy, width, fx) + img.shape[2:])
-        return blocks.mean(axis=(1, 3), dtype=np.float32)
+        acc = np.zeros((height, width) + img.shape[2:], np.float32)
+        for dy in range(fy):
+            for dx in range(fx):
+                acc = acc + blocks[:, dy, :, dx]
+        return acc * np.float32(1.0 / (fx * fy))
     out = np.tensordot(_area_weights(h, height), img, axes=(1, 0))
     return np.moveaxis(np.tensordot(_area_weights(w, width), out, axes=(1, 1)), 0, 1).astype(np.float32)
 

@@ -33,6 +33,39 @@ def test_resamplers():
     np.testing.assert_array_equal(D.resize_nearest(depth, 4, 4), depth[[0, 3, 6, 9]][:, [0, 4, 8, 12]])
 
 
+def test_inter_area_integer_factor_follows_opencv_float_rule():
+    """cv2.resize(float32 image, INTER_AREA) at an integer factor (the reference's only non-debug use:
+    load_messytable.py:148-157 /2, load_blender.py:107-119 /4, on images already divided by 255): the f x f block summed in
+    float32, rows outer / columns inner, times float32(1 / f^2) - no 8-bit rounding anywhere (the inputs are float).
+    A hand-computed 4x4 -> 2x2 case whose fp32 result depends on that order (1e8 + 1 - 1e8 is 0 in fp32, 1 in exact
+    arithmetic), a .5 tie of 8-bit pixel values that must NOT be rounded, and the /4 path.  The resamplers stay "parity
+    unpinned": the reference's loaders cannot run here (cv2 / imageio absent) and the reference holds no fixtures for them."""
+    from nerf import datasets as D
+    big = np.float32(1e8)
+    img = np.array([[big, 1.0, 0.0, 0.0],
+                    [-big, 0.0, 0.0, 2.0],
+                    [3.0, 4.0, 10 / 255, 11 / 255],
+                    [5.0, 6.0, 11 / 255, 11 / 255]], np.float32)
+    out = D.resize_area(img, 2, 2)
+    f = np.float32
+    expect = np.array([[((f(big) + f(1.0)) + f(-big) + f(0.0)) * f(0.25), f(2.0) * f(0.25)],
+                       [f(18.0) * f(0.25), (((f(10 / 255) + f(11 / 255)) + f(11 / 255)) + f(11 / 255)) * f(0.25)]], np.float32)
+    assert float(expect[0, 0]) == 0.0            # the sequential fp32 sum loses the 1 (a pairwise / float64 sum would give 0.25)
+    np.testing.assert_array_equal(out, expect)
+    assert abs(float(out[1, 1]) * 255 - 10.75) < 1e-5   # an 8-bit .75 (or .5) mean stays fractional: float path
+    img16 = np.arange(8 * 8, dtype=np.float32).reshape(8, 8) / 7
+    out4 = D.resize_area(img16, 2, 2)
+    acc = np.zeros((2, 2), np.float32)
+    blocks = img16.reshape(2, 4, 2, 4)
+    for dy in range(4):
+        for dx in range(4):
+            acc = acc + blocks[:, dy, :, dx]
+    np.testing.assert_array_equal(out4, acc * np.float32(1 / 16))
+    # three channels ride along unchanged
+    rgb = np.stack([img, img * 2, img * 0.5], -1)
+    np.testing.assert_array_equal(D.resize_area(rgb, 2, 2)[..., 0], expect)
+
+
 def _write_blender(root, n_frames=(3, 2, 4), size=8):
     rng = np.random.default_rng(1)
     frames = {}

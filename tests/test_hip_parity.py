@@ -1270,3 +1270,61 @@ def test_one_call_training_path_equals_stage_composition(golden, dev, precision,
         assert float((grads_s[k] - grads_b[k]).abs().max()) <= 2e-5 * scale, k
     lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + 4 * bucket.flat.numel()
     assert all(lo <= p.grad.data_ptr() < hi for p in bucket.params)
+
+
+def test_inputs_that_require_grad_take_the_differentiable_path(golden, dev):
+    """Pose / ray optimisation: points or rays that require grad must GET a gradient.  The fused training kernels
+    differentiate w.r.t. the parameters only, so such calls run the torch encoding + nn.Linear composition (and FusedNetFn
+    refuses them loudly rather than returning None); values agree with the fused path, and d(out)/d(pts) matches a central
+    finite difference of the fused forward."""
+    import nerf
+    from nerf import _train
+    name = "render_lego_val"
+    g = golden(name)
+    mkw, wfn, _ = CASES[name]
+    mc, _ = make_models(mkw, *wfn(), dev)
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    pts = G(g["pts_coarse"][:8, :16], dev).clone().requires_grad_(True)
+    rd = G(g["rd"][:8], dev)
+    rays = torch.cat([torch.zeros(8, 8, device=dev), torch.nn.functional.normalize(rd, dim=-1)], -1)
+    out = nerf.run_network(mc, pts, rays, 4096, ex, ed)
+    with torch.no_grad():
+        fused = nerf.run_network(mc, pts.detach(), rays, 4096, ex, ed)
+    assert rel_err(C(out), C(fused)) < 1e-4
+    w = torch.linspace(0.5, 1.5, out.numel(), device=dev).reshape(out.shape)
+    (out * w).sum().backward()
+    assert pts.grad is not None and bool(torch.isfinite(pts.grad).all()) and float(pts.grad.abs().max()) > 0
+    assert all(p.grad is not None for p in mc.parameters())
+    # central difference along one coordinate of one point, through the fused (exact-fp32) forward
+    eps = 1e-3
+    with torch.no_grad():
+        d = torch.zeros_like(pts); d[3, 5, 1] = eps
+        fd = ((nerf.run_network(mc, pts.detach() + d, rays, 4096, ex, ed) - nerf.run_network(mc, pts.detach() - d, rays, 4096, ex, ed)) * w).sum() / (2 * eps)
+    assert abs(float(fd) - float(pts.grad[3, 5, 1])) < 2e-2 * max(abs(float(fd)), 1.0)
+    with pytest.raises(RuntimeError):
+        _train.FusedNetFn.apply(mc, pts.reshape(-1, 3), rays[:, -3:], 16, True, True, *[p for m in mc.linear_modules() for p in (m.weight, m.bias)])
+
+
+def test_second_device_gets_its_own_launch_attributes():
+    """hipFuncAttributeMaxDynamicSharedMemorySize is per device: a process that launches the > 64 KiB-LDS kernels on
+    a second GPU must set it there too.  Needs two visible GPUs (the gpurun boxes have one: skipped there)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    import nerf
+    from nerf import _ops, synthetic as syn
+    kw = CASES["render_d8w256_val"][0]
+    sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(42, **kw).items()}
+    outs = []
+    nerf.set_precision("bf16")
+    try:
+        for idx in (0, 1):
+            d = torch.device("cuda", idx)
+            with torch.cuda.device(d):
+                m = nerf.models.FlexibleNeRFModel(**kw); m.load_state_dict(sd); m = m.to(d)
+                pts = torch.linspace(-1, 1, 3 * 1000, device=d).reshape(1000, 3)
+                vd = torch.nn.functional.normalize(torch.ones(1000, 3, device=d), dim=-1)
+                with torch.no_grad():
+                    outs.append(_ops.run_network_pts(m.packed(), pts, vd, 1).cpu())
+    finally:
+        nerf.set_precision("fp32")
+    assert torch.equal(outs[0], outs[1])

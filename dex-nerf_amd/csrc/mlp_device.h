@@ -448,9 +448,10 @@ struct Pipe {
 #ifdef DN_EXP_NOSETTLE   // timing experiment only (UNSAFE: phi copies may read fragments in flight)
     return;
 #endif
-    static_assert(kPrefetch == 2 || kPrefetch == 3, "settle() names every FIFO entry");
+    static_assert(kPrefetch >= 2 && kPrefetch <= 4, "settle() names every FIFO entry");
     if constexpr (kPrefetch == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bias_nxt));
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[kPrefetch - 1]), "+v"(bias_nxt));
+    else if constexpr (kPrefetch == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(bias_nxt));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[kPrefetch - 1]), "+v"(bias_nxt));
   }
 #else
   __device__ __forceinline__ void settle() {}

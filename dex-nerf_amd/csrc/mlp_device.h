@@ -378,14 +378,67 @@ struct Pipe {
 #endif
   }
 
+#if defined(DN_PIPE_ASM_READS) && defined(DN_PIPE_LEADER_DMA)
+  // ---- one workgroup barrier per TWO phases (PH = 32: the fixed-shape W = 256 instance, where the parity of a phase is a
+  // compile-time position).  The barrier is the one cost of the ring that cannot be overlapped: the SIMD partners do not share
+  // the matrix pipe fairly, the older wave parks ~630 cycles at every barrier and the younger one then runs alone.
+  // EVEN phase p: every DMA of ours has landed (vmcnt(0): phases <= p+2), barrier, then this wave (0-3) fetches phase p+3 at
+  // once and phase p+4 at mid-phase - into the slots of phases p-2 and p-1, which every wave has left.  ODD phase: nothing but
+  // the slot rotation.  The ring holds p, p+1, p+2 landed and p+3, p+4 in flight: 5 slots; flight time 1.5-2 phases (~1.5 us).
+  template <bool EVEN>
+  __device__ __forceinline__ void phase_begin2() {
+#if defined(DN_STAMP) && DN_STAMP == 2
+    if (st_top_pending) { st_top += stamp() - st_last; st_top_pending = 0; ++st_n; }
+#endif
+    if constexpr (EVEN) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      advance_issue();
+      dma_phase(pend_src, pend_dst, wave < 4 ? 1u : 0u);
+      dma_phase(pend_src + PER_WAVE * kPieceBytes, pend_dst + PER_WAVE * kPieceBytes, wave < 4 ? 1u : 0u);
+    }
+    slot_nxt = (slot_nxt + 1 == kRingPhases) ? 0 : slot_nxt + 1;
+    rda_cur = slot_cur_base + lane16;
+    slot_cur_base = __builtin_amdgcn_readfirstlane(ring_addr + slot_nxt * kSlotBytes);
+  }
+  template <bool EVEN>
+  __device__ __forceinline__ void mid_phase2() {
+    if constexpr (EVEN) {
+      advance_issue();
+      dma_phase(pend_src, pend_dst, wave < 4 ? 1u : 0u);
+      dma_phase(pend_src + PER_WAVE * kPieceBytes, pend_dst + PER_WAVE * kPieceBytes, wave < 4 ? 1u : 0u);
+    }
+  }
+#endif
+  // phase boundary / mid-phase hooks at position POS of a stream whose barrier period is PH pieces (16, or 32: see above)
+  template <int PH, int POS>
+  __device__ __forceinline__ void at_position() {
+    if constexpr (POS % kPhasePieces == 0) {
+#if defined(DN_PIPE_ASM_READS) && defined(DN_PIPE_LEADER_DMA)
+      if constexpr (PH == 2 * kPhasePieces) phase_begin2<(POS % PH) == 0>();
+      else phase_begin();
+#else
+      phase_begin();
+#endif
+    }
+    if constexpr (POS % kPhasePieces == kPhasePieces / 2) {
+#if defined(DN_PIPE_ASM_READS) && defined(DN_PIPE_LEADER_DMA)
+      if constexpr (PH == 2 * kPhasePieces) mid_phase2<(POS % PH) == kPhasePieces / 2>();
+      else mid_phase();
+#else
+      mid_phase();
+#endif
+    }
+  }
+
   // Padding pieces (the stream is padded to whole phases): advance the FIFO over N pieces starting at position
   // POS without issuing MFMAs, so the next tile pass starts again at position 0 of a fresh phase.
-  template <int POS, int N>
+  template <int POS, int N, int PH = kPhasePieces>
   __device__ __forceinline__ void skip() {
     static_for<N>([&](auto i_c) {
       constexpr int pos = POS + decltype(i_c)::value;
       static_assert(pos % kPhasePieces != 0 || decltype(i_c)::value == 0, "padding never crosses a phase");
-      if constexpr (pos % kPhasePieces == kPhasePieces / 2) mid_phase();
+      if constexpr (pos % kPhasePieces == kPhasePieces / 2) at_position<PH, pos>();
 #ifdef DN_PIPE_ASM_READS
       // only the last kPrefetch skipped positions fetch pieces that will be consumed (the first pieces of the next pass);
       // with fewer padding pieces than FIFO entries the stage before has already fetched the rest (run_stage48, PAD)

@@ -52,7 +52,8 @@ constexpr int g48_issued(int q0, int q1) {
 // three MFMAs, read A(p+2); the next tile's bias read goes out right after the A read of step KT-2, i.e. between A(next
 // tile, 0) and A(next tile, 1) - so with a FIFO of P pieces the wait counts are P - 1 everywhere and P at k = KT-1; the
 // bias take at k = 0 waits with 1 (one A read was issued after the bias read), which also lands every older A read.
-template <int F, int NT_OUT, int KH, int KP, int POS0, bool LAST = false, bool SETTLE = true, int PAD = 0, class PipeT, class BH, class BP, class Emit>
+template <int F, int NT_OUT, int KH, int KP, int POS0, bool LAST = false, bool SETTLE = true, int PAD = 0, int PH = kPhasePieces, class PipeT, class BH,
+          class BP, class Emit>
 __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, unsigned bias_addr, unsigned next_addr, Emit&& emit) {
   constexpr int PT = 3, KT = KH + KP;
   static_assert(KT >= 2, "the bias prefetch distance assumes at least two pieces per tile");
@@ -65,8 +66,7 @@ __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, 
 #if defined(DN_STAMP) && DN_STAMP == 1
       if constexpr (pos % 4 == 0 && pos % kPhasePieces != 0) pipe.template substamp<(pos % kPhasePieces) / 4>();
 #endif
-      if constexpr (pos % kPhasePieces == 0) pipe.phase_begin();
-      if constexpr (pos % kPhasePieces == kPhasePieces / 2) pipe.mid_phase();
+      pipe.template at_position<PH, pos>();   // phase boundary (barrier + weight DMA) / mid-phase DMA, if this is one
 #ifdef DN_PIPE_ASM_READS
       if constexpr (k == 0) {
         const f32x4 b = pipe.template bias_take<1>();   // issued before A(pos + 1): one younger read may stay in flight
@@ -172,6 +172,13 @@ template <int W, int F, int DC = 0, unsigned MASKC = 0, int VIEWC = 0>
 __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdParams p, G48Params q) {
   constexpr bool FIXED = DC > 0;
   constexpr bool ST = !FIXED;   // settle at stage ends
+#if defined(DN_PIPE_ASM_READS) && defined(DN_PIPE_LEADER_DMA) && !defined(DN_G48_BARRIER_EVERY_PHASE)
+  // barrier period in pieces: every second phase where a phase's parity is a compile-time position - the fixed-shape W = 256
+  // instance (every stage boundary of D8 / skip 4 falls on an even phase, 74 phases per pass) - every phase elsewhere
+  constexpr int PH = (FIXED && W == 256) ? 2 * kPhasePieces : kPhasePieces;
+#else
+  constexpr int PH = kPhasePieces;
+#endif
   using BP8 = typename Prec<F>::BPiece;
   using Elem = typename Prec<F>::Elem;
   constexpr int PT = 3;
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
   pipe.slot_wr = 0;
   pipe.wave = wave;
 #pragma unroll
-  for (int ph = 0; ph < kRingPhases - 1; ++ph) pipe.issue_phase();
+  for (int ph = 0; ph < (PH == kPhasePieces ? kRingPhases - 1 : kRingPhases - 2); ++ph) pipe.issue_phase();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   pipe.slot_nxt = 0;
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       for (int t = 0; t < PT; ++t)
 #pragma unroll
         for (int k = 0; k < KXP; ++k) pe[t][k] = pe_xyz(t, k);
-      run_stage48<F, NT, KXP, 0, 0, false, ST>(pipe, pe, no_pe, bias_at(0), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
+      run_stage48<F, NT, KXP, 0, 0, false, ST, 0, PH>(pipe, pe, no_pe, bias_at(0), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
         emit48<F, false, decltype(nt_c)::value>(acc, ba[decltype(t_c)::value]);
       });
     }
@@ -343,10 +350,10 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     auto heads = [&](const BP8 (&hx)[PT][KH], BP8 (&hy)[PT][KH], auto view_c) __attribute__((always_inline)) {
       if constexpr (decltype(view_c)::value) {
         // ---- fc_alpha (its own 16-row tile, row 0, streamed first) + fc_feat with ReLU (models.py:248-249) ----
-        run_stage48<F, 1, KH, 0, 0, false, ST>(pipe, hx, no_pe, bias_at(bias_tile), 0u, [&](auto, auto t_c, const f32x4& acc) {
+        run_stage48<F, 1, KH, 0, 0, false, ST, 0, PH>(pipe, hx, no_pe, bias_at(bias_tile), 0u, [&](auto, auto t_c, const f32x4& acc) {
           out4[decltype(t_c)::value][3] = acc[0];  // row 0 lives in lane group 0, register 0
         });
-        run_stage48<F, NT, KH, 0, KH % kPhasePieces, false, ST>(pipe, hx, no_pe, bias_at(bias_tile + 1), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
+        run_stage48<F, NT, KH, 0, KH % PH, false, ST, 0, PH>(pipe, hx, no_pe, bias_at(bias_tile + 1), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
           emit48<F, true, decltype(nt_c)::value>(acc, hy[decltype(t_c)::value]);
         });
         bias_tile += NT + 1;
@@ -376,28 +383,31 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- layers_dir[0] on cat(feat, view) -> W/2, ReLU (models.py:250-252) ----
-        constexpr int POS_D = ((NT + 1) * KH) % kPhasePieces;
+        constexpr int POS_D = ((NT + 1) * KH) % PH;
         BP8 bg[PT][KH / 2];
         BP8 ped[PT];
 #pragma unroll
         for (int t = 0; t < PT; ++t) ped[t] = *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes);
         auto pe_dir = [&](int t, int) { return ped[t]; };
-        run_stage48<F, NT / 2, KH, KDP, POS_D, false, ST>(pipe, hy, pe_dir, bias_at(bias_tile), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
+        run_stage48<F, NT / 2, KH, KDP, POS_D, false, ST, 0, PH>(pipe, hy, pe_dir, bias_at(bias_tile), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
           emit48<F, true, decltype(nt_c)::value>(acc, bg[decltype(t_c)::value]);
         });
         bias_tile += NT / 2;
         // ---- fc_rgb (models.py:253) ----
-        constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % kPhasePieces;
+        constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % PH;
         constexpr int END = POS_R + KH / 2;
-        static_assert(END <= kPhasePieces, "the tail stays inside one phase");
-        run_stage48<F, 1, KH / 2, 0, POS_R, true, ST, (kPhasePieces - END) % kPhasePieces>(pipe, bg, no_pe, bias_at(bias_tile), bias_at(0), [&](auto, auto t_c, const f32x4& acc) {
+        static_assert(END <= PH && (END - 1) / kPhasePieces == POS_R / kPhasePieces, "the tail stays inside one phase");
+        constexpr int PAD_R = (kPhasePieces - END % kPhasePieces) % kPhasePieces;
+        static_assert((END + PAD_R) % PH == 0, "a tile pass is a whole number of barrier periods");
+        run_stage48<F, 1, KH / 2, 0, POS_R, true, ST, PAD_R, PH>(pipe, bg, no_pe, bias_at(bias_tile), bias_at(0), [&](auto, auto t_c, const f32x4& acc) {
           constexpr int t = decltype(t_c)::value;
           out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2];
         });
-        if constexpr (END % kPhasePieces != 0) pipe.template skip<END, kPhasePieces - END>();   // (settles at its end)
+        if constexpr (PAD_R != 0) pipe.template skip<END, PAD_R, PH>();   // (settles at its end)
         else pipe.settle();
       } else {
         // ---- fc_out (models.py:256) ----
+        static_assert(PH == kPhasePieces, "no-viewdirs nets run the every-phase barrier");
         run_stage48<F, 1, KH, 0, 0, true, ST, (kPhasePieces - KH % kPhasePieces) % kPhasePieces>(pipe, hx, no_pe, bias_at(bias_tile), bias_at(0), [&](auto, auto t_c, const f32x4& acc) {
           constexpr int t = decltype(t_c)::value;
           out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2]; out4[t][3] = acc[3];
@@ -408,6 +418,8 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     };
     // ---- trunk (models.py:239-246): the activations ping-pong between two register sets ----
     if constexpr (FIXED) {
+      static_assert((NT * KXP) % PH == 0 && (NT * KH) % PH == 0 && (NT * (KH + KXP)) % PH == 0,
+                    "layer1 and every trunk layer span whole barrier periods: each stage starts at position 0 of one");
       static_for<DC - 1>([&](auto i_c) {
         constexpr int i = decltype(i_c)::value;
         auto& bin = (i % 2 == 0) ? ba : bb;
@@ -415,17 +427,17 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         auto emit = [&](auto nt_c, auto t_c, const f32x4& acc) { emit48<F, true, decltype(nt_c)::value>(acc, bout[decltype(t_c)::value]); };
         if constexpr ((MASKC >> i) & 1u) {
 #ifdef DN_G48_SKIP_PE_FROM_LDS
-          run_stage48<F, NT, KH, KXP, 0, false, false>(pipe, bin, pe_xyz, bias_at(bias_tile), 0u, emit);
+          run_stage48<F, NT, KH, KXP, 0, false, false, 0, PH>(pipe, bin, pe_xyz, bias_at(bias_tile), 0u, emit);
 #else
           BP8 pe[PT][KXP];   // the skip layer's second K panel, in registers for the stage (see layer1)
 #pragma unroll
           for (int t = 0; t < PT; ++t)
 #pragma unroll
             for (int k = 0; k < KXP; ++k) pe[t][k] = pe_xyz(t, k);
-          run_stage48<F, NT, KH, KXP, 0, false, false>(pipe, bin, [&](int t, int k) { return pe[t][k]; }, bias_at(bias_tile), 0u, emit);
+          run_stage48<F, NT, KH, KXP, 0, false, false, 0, PH>(pipe, bin, [&](int t, int k) { return pe[t][k]; }, bias_at(bias_tile), 0u, emit);
 #endif
         } else {
-          run_stage48<F, NT, KH, 0, 0, false, false>(pipe, bin, no_pe, bias_at(bias_tile), 0u, emit);
+          run_stage48<F, NT, KH, 0, 0, false, false, 0, PH>(pipe, bin, no_pe, bias_at(bias_tile), 0u, emit);
         }
         bias_tile += NT;
       });

@@ -56,7 +56,7 @@ class FusedNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, pts, viewdirs, samples_per_ray, log_xyz, log_dir, *params):
         """`pts` (P,3) + `viewdirs` (N,3), or - when `samples_per_ray` is None - packed ray rows (N,11) + depths (N,S)."""
-        if inputs_need_grad(pts, viewdirs):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:   # (inside forward the tensors themselves are detached views)
             raise RuntimeError("FusedNetFn differentiates w.r.t. the model parameters only; points / rays / view directions that "
                                "require grad must go through the nn.Linear composition (run_network does that by itself)")
         pk = model.packed(log_xyz, log_dir)

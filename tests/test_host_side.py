@@ -184,7 +184,7 @@ def test_committed_bench_line_follows_the_contract():
     """The bench line committed under profiles/ (written by bench.py on an MI355X) carries every field the driver's
     contract names, with the roofline and cpu_baseline objects."""
     import json
-    path = os.path.join(REPO, "profiles", "r01_final_bench_bf16.json")
+    path = os.path.join(REPO, "profiles", "r02_bench_bf16.json")
     line = json.loads(open(path).read().strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -194,6 +194,12 @@ def test_committed_bench_line_follows_the_contract():
     roof = line["roofline"]
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert roof["traffic"] is None or roof["traffic"] > 0
+    # round 2 additions: measured-traffic fields, Dex agreement next to the PSNR, the exact-fp32 mode, the training roofline
+    assert roof["algorithmic_bytes"] == 160000 * 192 * 20 + 160000 * 44
+    assert 0.0 < line["dex_vs_oracle"]["agree_frac"] <= 1.0 and line["dex_vs_oracle"]["worst_miss_m"] >= 0.0
+    assert line["fp32_mode"]["frac"] == pytest.approx(line["fp32_mode"]["tflops"] / 157.3)
+    tr = line["train"]["roofline"]
+    assert tr["bound"] == "hbm" and tr["unit"] == "GB/s" and abs(tr["frac"] - tr["achieved"] / tr["peak"]) < 1e-9
     cb = line["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     # value = rays of all ranks / time: consistent with ms_per_step

@@ -321,9 +321,9 @@ __global__ __launch_bounds__(256) void sampler_kernel(const float* __restrict__ 
     for (int i = lane; i < L; i += 64) w[i] = weights[ray * nc + 1 + i] + 1e-5f;
     for (int i = lane; i < nc; i += 64) sbuf[i] = zc[i];
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();   // (this wave's own rows: DS instructions of a wave execute in order)
   build_cdf(w, cdf, B);
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   for (int q = lane; q < nf; q += 64) {
     const float uq = (u != nullptr) ? u[ray * nf + q] : linspace_elem(0.0f, 1.0f, nf, q);
     int ind;
@@ -335,12 +335,58 @@ __global__ __launch_bounds__(256) void sampler_kernel(const float* __restrict__ 
     if (MODE == 1) sbuf[B + 1 + q] = s;
   }
   if (MODE == 1) {
-    const int total = B + 1 + nf;
+    const int nc = B + 1;
+    const int total = nc + nf;
+    // Everything below touches this wave's own LDS rows only: a wave's DS instructions execute in order, so no workgroup
+    // barrier is needed between the steps (the round-1 kernel had one per bitonic stage: 36 for 192 depths).
+    __builtin_amdgcn_wave_barrier();
+    // sort(cat(z_coarse, z_samples)) (train_utils.py:173).  Both halves are usually already ascending - the coarse depths
+    // always, the samples whenever u is ascending (deterministic resampling: every validation render) - and then the sort is
+    // a MERGE: an element's output slot = its own index + the number of elements of the other half in front of it (coarse
+    // depths first on ties), found by binary search.  192 depths: ~7 LDS reads per element instead of 36 compare-exchange
+    // stages.  Whether the samples really are ascending is checked on the values (an interpolated sample can land an ulp past
+    // its bin edge); anything else takes the bitonic sort, which produces the same multiset in the same order.
+    const float* zs = sbuf + nc;
+    bool ordered = true;
+    for (int q = lane; q < nf; q += 64)
+      if (q + 1 < nf && zs[q] > zs[q + 1]) ordered = false;
+    for (int i = lane; i < nc; i += 64)
+      if (i + 1 < nc && sbuf[i] > sbuf[i + 1]) ordered = false;
+    constexpr int kMergeCoarse = 4, kMergeFine = 8;   // merge path: up to 256 coarse + 512 fine depths (values held in registers)
+    if (nc <= 64 * kMergeCoarse && nf <= 64 * kMergeFine && __all(ordered)) {
+      float vc[kMergeCoarse], vf[kMergeFine];
+      int sc[kMergeCoarse], sf[kMergeFine];
+#pragma unroll
+      for (int e = 0; e < kMergeCoarse; ++e) {        // coarse depth i: samples strictly in front of it
+        const int i = lane + 64 * e;
+        const float v = sbuf[min(i, nc - 1)];
+        int lo = 0, hi = nf;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (zs[mid] < v) lo = mid + 1; else hi = mid; }
+        vc[e] = v; sc[e] = i + lo;
+      }
+#pragma unroll
+      for (int e = 0; e < kMergeFine; ++e) {          // sample q: coarse depths in front of it or equal to it
+        const int q = lane + 64 * e;
+        const float v = zs[min(q, nf - 1)];
+        int lo = 0, hi = nc;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sbuf[mid] <= v) lo = mid + 1; else hi = mid; }
+        vf[e] = v; sf[e] = q + lo;
+      }
+      __builtin_amdgcn_wave_barrier();   // every search has read its operands (one wave, in order): now overwrite in place
+#pragma unroll
+      for (int e = 0; e < kMergeCoarse; ++e) if (lane + 64 * e < nc) sbuf[sc[e]] = vc[e];
+#pragma unroll
+      for (int e = 0; e < kMergeFine; ++e) if (lane + 64 * e < nf) sbuf[sf[e]] = vf[e];
+      __builtin_amdgcn_wave_barrier();
+      if (live)
+        for (int i = lane; i < total; i += 64) z_fine[ray * total + i] = sbuf[i];
+      return;
+    }
     for (int i = total + lane; i < sort_len; i += 64) sbuf[i] = __builtin_inff();
-    // bitonic sort of sort_len (power of two) floats by one wave; block-uniform trip counts
+    // bitonic sort of sort_len (power of two) floats by one wave
     for (int k = 2; k <= sort_len; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         for (int t = lane; t < (sort_len >> 1); t += 64) {
           const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
           const int hi = lo | j;
@@ -353,7 +399,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(const float* __restrict__ 
         }
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     if (live)
       for (int i = lane; i < total; i += 64) z_fine[ray * total + i] = sbuf[i];
   }

@@ -254,13 +254,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if os.environ.get("DEXNERF_DIST_BACKEND", "nccl") != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)      # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # under torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" is RCCL on ROCm.  DEXNERF_DIST_BACKEND=gloo lets the N > 1 leg be rehearsed with several ranks on ONE GPU
+        # (RCCL refuses two ranks on the same device); ranks then share cuda:0
+        backend = os.environ.get("DEXNERF_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus} but the RCCL process group has {dist.get_world_size()} ranks")
 

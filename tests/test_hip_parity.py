@@ -1328,3 +1328,26 @@ def test_second_device_gets_its_own_launch_attributes():
     finally:
         nerf.set_precision("fp32")
     assert torch.equal(outs[0], outs[1])
+
+
+def test_bench_multi_gpu_leg_rehearsal_two_ranks_one_gpu(dev):
+    """`bench.py --gpus 2` under torch.distributed.run, as the driver launches it, with two gloo ranks sharing this GPU (RCCL
+    refuses two ranks on one device): the render timing, the data-parallel training step (`train_dp`: broadcast, per-network
+    all-reduce through the FlatGradBucket, fused Adam) and the one JSON line on rank 0.  Numbers are meaningless here (one GPU,
+    gloo); the path must run and the line must carry the fields the N > 1 contract asks for."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, DEXNERF_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["unit"] == "rays/s" and "cpu_baseline" not in line
+    assert abs(line["value"] - 2 * 160000 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+    dp = line["train_dp"]
+    assert dp["n_gpus"] == 2 and dp["rccl_ranks"] == 2 and dp["allreduce_bytes"] == 2 * 595844 * 4
+    assert dp["rays_per_s"] > 0 and dp["allreduce_ms"] > 0 and dp["roofline"]["bound"] == "hbm"

@@ -50,6 +50,22 @@ def test_argument_validation_needs_no_gpu(hiplib):
     assert hiplib.dn_coarse_depths(None, 11, 4, 64, 0, None, None, None) == -1000
     assert hiplib.dn_sample_pdf(None, None, None, 1, 64, 8, None, None, None) == -1000
     assert hiplib.dn_render_workspace_bytes(1000, 64, 128) >= 1000 * (64 * 6 + 192 * 5) * 4
+    # the training pair: its workspace adds the gradient scratch of one network; NULL / misaligned
+    # arguments and an unknown `nets` mask are refused before anything is enqueued
+    ws_train = hiplib.dn_render_train_workspace_bytes(1000, 64, 128)
+    assert ws_train >= hiplib.dn_render_workspace_bytes(1000, 64, 128) + 1000 * 192 * 4 * 4
+    assert hiplib.dn_render_train_workspace_bytes(-1, 64, 128) == 0
+    null = None
+    assert hiplib.dn_render_rays_train(ctypes.byref(d), null, ctypes.byref(d), null, 1, null, 11, 4, 64, 128, 0, 0.0, 0, None, 0,
+                                       null, null, null, null, null, null, null, null, null, null, null, null, null, null,
+                                       null, null, null) == -1000
+    assert b"dn_render_rays_train" in hiplib.dn_last_error()
+    assert hiplib.dn_render_rays_backward(ctypes.byref(d), null, ctypes.byref(d), null, 1, null, 11, 4, 64, 128, 0.0, 0, null, null,
+                                          null, null, null, null, null, null, null, null, null, null, null, null, null,
+                                          None, None, None, None, 3, null) == -1000
+    assert hiplib.dn_render_rays_train(ctypes.byref(d), null, ctypes.byref(d), null, 1, null, 11, 0, 64, 128, 0, 0.0, 0, None, 0,
+                                       null, null, null, null, null, null, null, null, null, null, null, null, null, null,
+                                       null, null, null) == 0     # zero rays: nothing to do
     with pytest.raises(RuntimeError):
         _hip.check(-1000, "probe")
 

@@ -93,8 +93,9 @@ struct FwdParams {
   // [tile32][mask_words][64 lanes][16 B]; slots as in TrainLayout
   char* act;
   char* masks;
-  int act_pieces, mask_words;
+  int act_pieces, mask_words;   // (SAVE == 2, 8-bit saved tensors: act_pieces counts 1 KiB units = pairs of pieces)
   int slot_xyz, slot_dir, slot_layer1, slot_trunk0, slot_feat, slot_dirout;
+  int save8;   // training forward: store the saved pieces at 8 bits (DN_PREC_BF16_S8)
 };
 
 // ---- weight pipeline: LDS ring fed by LDS-DMA -------------------------------------------------------
@@ -651,6 +652,28 @@ __device__ __forceinline__ void store16_uniform(const char* base, unsigned lane1
 #endif
   asm volatile("s_nop 4\n\tglobal_store_dwordx4 %[voff], %[data], %[sbase]" DN_STORE_POLICY "\n\ts_nop 1"
                : : [voff] "v"(voff), [data] "v"(data), [sbase] "s"(b) : "memory");
+}
+
+// ---- 8-bit saved tensors (DN_PREC_BF16_S8): a bf16 B piece (8 values per lane) -> 8 bytes --------------------------
+// GRAD = false: e4m3 (activations, post-ReLU, O(1)); GRAD = true: e5m2 of value * scale, saturated (e5m2 has infinities).
+// From the bf16 values the kernel itself used (exact in fp32), so the stored bytes equal convert_s8_kernel's on the bf16 buffers.
+template <bool GRAD>
+__device__ __forceinline__ void piece_to_8bit(const bf16x8& v, float scale, unsigned& w0, unsigned& w1) {
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    f[e] = static_cast<float>(v[e]);
+    if constexpr (GRAD) f[e] = fminf(fmaxf(f[e] * scale, -57344.0f), 57344.0f);
+  }
+  int a = 0, b = 0;
+  if constexpr (GRAD) {
+    a = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], a, false); a = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], a, true);
+    b = __builtin_amdgcn_cvt_pk_bf8_f32(f[4], f[5], b, false); b = __builtin_amdgcn_cvt_pk_bf8_f32(f[6], f[7], b, true);
+  } else {
+    a = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], a, false); a = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], a, true);
+    b = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], b, false); b = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], b, true);
+  }
+  w0 = static_cast<unsigned>(a); w1 = static_cast<unsigned>(b);
 }
 
 // ---- positional encoding straight into B-piece layout -------------------------------------------------

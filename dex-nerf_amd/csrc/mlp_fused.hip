@@ -25,7 +25,7 @@ namespace dn {
 
 // SAVE = training forward: every stage's output pieces (and both encodings) are also written to `p.act` in the
 // wave-native piece layout, plus one 128-bit ReLU mask word per lane per masked stage to `p.masks`.
-template <int W, int LX, int LD, int BF16, int PT, bool SAVE>
+template <int W, int LX, int LD, int BF16, int PT, int SAVE>   // SAVE: 0 inference, 1 training forward (bf16 / fp32 pieces), 2 training forward with 8-bit saved pieces
 __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2 : 1)) void mlp_forward_kernel(FwdParams p) {
   using P = Prec<BF16>;
   using BPiece = typename P::BPiece;
@@ -186,11 +186,24 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
     auto save_piece = [&](int t, int slot, const BPiece& v) {
       store16_uniform(act_tile[t] + static_cast<long long>(slot) * kPieceBytes, pipe.lane16, v);
     };
+    // SAVE == 2: pieces `slot` (even) and `slot + 1` as ONE 1 KiB unit of 8 + 8 bytes per lane (e4m3)
+    auto save_pair = [&](int t, int slot, const BPiece& lo, const BPiece& hi) {
+      if constexpr (SAVE == 2 && BF16 == 1) {
+        unsigned w[4];
+        piece_to_8bit<false>(lo, 1.0f, w[0], w[1]);
+        piece_to_8bit<false>(hi, 1.0f, w[2], w[3]);
+        store16_uniform(act_tile[t] + static_cast<long long>(slot >> 1) * kPieceBytes, pipe.lane16, make_uint4(w[0], w[1], w[2], w[3]));
+      }
+    };
     // (the piece arrays are passed by reference to their array type and indexed with compile-time constants only: a
     // decayed pointer sends the whole register-resident activation set to scratch memory in the fp32 instances)
     auto save_pieces = [&](auto nt_c, int t, int slot0, const auto& pieces) {
 #ifndef DN_EXP_NOSAVE
-      if constexpr (SAVE) {
+      if constexpr (SAVE == 2) {
+        constexpr int nt = decltype(nt_c)::value;
+        static_assert(P::PPT == 2, "8-bit saved tensors pair the two pieces of a 32-row tile");
+        save_pair(t, slot0 + nt * 2, pieces[nt * 2], pieces[nt * 2 + 1]);
+      } else if constexpr (SAVE) {
         constexpr int nt = decltype(nt_c)::value;
         static_for<P::PPT>([&](auto s_c) {
           constexpr int s2 = decltype(s_c)::value;
@@ -239,12 +252,24 @@ __global__ __launch_bounds__((waves_of<BF16, PT>() * 64), ((BF16 && PT == 1) ? 2
     if constexpr (SAVE) {
 #pragma unroll
       for (int t = 0; t < PT; ++t) {
+        if constexpr (SAVE == 2) {
+          static_assert(KXP % 2 == 0 && KDP % 2 == 0, "encoding panels are whole units");
+#pragma unroll
+          for (int k = 0; k < KXP; k += 2) save_pair(t, p.slot_xyz + k, pe_xyz(t, k), pe_xyz(t, k + 1));
+          if (p.use_viewdirs) {
+#pragma unroll
+            for (int k = 0; k < KDP; k += 2)
+              save_pair(t, p.slot_dir + k, *reinterpret_cast<const BPiece*>(ped + (t * KDP + k) * kPieceBytes),
+                        *reinterpret_cast<const BPiece*>(ped + (t * KDP + k + 1) * kPieceBytes));
+          }
+        } else {
 #pragma unroll
         for (int k = 0; k < KXP; ++k) save_piece(t, p.slot_xyz + k, pe_xyz(t, k));
         if (p.use_viewdirs) {
 #pragma unroll
           for (int k = 0; k < KDP; ++k)
             save_piece(t, p.slot_dir + k, *reinterpret_cast<const BPiece*>(ped + (t * KDP + k) * kPieceBytes));
+        }
         }
       }
     }
@@ -445,7 +470,7 @@ __global__ void pack_kernel(NetLayout L, PackPtrs ptrs, char* __restrict__ packe
   }
 }
 
-template <int W, int LX, int LD, int BF16, int PT, bool SAVE = false>
+template <int W, int LX, int LD, int BF16, int PT, int SAVE = 0>
 static int launch_forward(FwdParams p, hipStream_t stream) {
   auto kern = mlp_forward_kernel<W, LX, LD, BF16, PT, SAVE>;
   constexpr int WAVES = waves_of<BF16, PT>();
@@ -474,6 +499,13 @@ int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStrea
   if ((bf || hf) && geom48 && bf16_pt == 1 && p.act == nullptr && p.mode != 2 && p.n_points < (1LL << 31) - 1024 && g48_supported(d, precision))
     return launch_forward48(d, precision, p, p.packed + p.bias_bytes + static_cast<size_t>(p.total_pieces) * kPieceBytes, stream);
   if (p.act != nullptr && hf) { set_error("mlp_forward(train): fp16 is a render-only mode"); return DN_E_UNSUPPORTED; }
+  if (p.act != nullptr && p.save8) {   // training forward with 8-bit saved pieces (bf16 arithmetic)
+    if (!bf) { set_error("mlp_forward(train, 8-bit saved tensors): bf16 arithmetic only"); return DN_E_UNSUPPORTED; }
+    if (d.num_encoding_fn_xyz == 10 && d.hidden_size == 256) return launch_forward<256, 10, 4, 1, 1, 2>(p, stream);
+    if (d.num_encoding_fn_xyz == 10 && d.hidden_size == 128) return launch_forward<128, 10, 4, 1, 1, 2>(p, stream);
+    set_error("mlp_forward(train): no kernel instance for W=%d L_xyz=%d", d.hidden_size, d.num_encoding_fn_xyz);
+    return DN_E_UNSUPPORTED;
+  }
   if (p.act != nullptr) {  // training forward: LX=10 nets, PT=1
     if (d.num_encoding_fn_xyz == 10 && d.hidden_size == 256)
       return bf ? launch_forward<256, 10, 4, true, 1, true>(p, stream) : launch_forward<256, 10, 4, false, 1, true>(p, stream);

@@ -325,7 +325,6 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     auto no_pe = [&](int, int) { return BP8{}; };
 
     BP8 ba[PT][KH], bb[PT][KH];
-    BP8 none[PT][1];
     int bias_tile = 0;
     // ---- layer1: xyz encoding -> W, no activation (models.py:238) ----
     // (the encoding pieces go into registers once per stage - bb is still free here: read through the pe_xyz lambda they

@@ -24,9 +24,12 @@ struct BwdParams {
   long long n_points;
   long long n_tiles;
   char* grads;             // [tile32][grad_pieces][64][16 B]
-  int grad_pieces;
+  int grad_pieces;         // (S8 kernels: 1 KiB units = pairs of pieces)
   int gslot_dirout, gslot_feat, gslot_trunk0, gslot_layer1, gslot_out;
+  float grad_scale;        // S8 kernels: the power of two the gradients are multiplied by before they are rounded to e5m2
 };
+
+static thread_local float g_s8_grad_scale = 65536.0f;   // dn_set_s8_grad_scale: gradient scale of the 8-bit saved tensors
 
 constexpr int kBwdWaveLds = 6 * kPieceBytes;  // per wave: 2 output-gradient slots + 4 mask-word slots (1 KiB each)
 
@@ -47,7 +50,7 @@ __device__ __forceinline__ void dma16_lanes(const void* src_lane, unsigned lds_a
       : "memory");
 }
 
-template <int W, int BF16>
+template <int W, int BF16, bool S8 = false>   // S8: the saved gradients at 8 bits (e5m2 x grad_scale), two pieces per 1 KiB unit
 __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void mlp_backward_kernel(BwdParams p) {
   using P = Prec<BF16>;
   using BPiece = typename P::BPiece;
@@ -109,7 +112,18 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
     const char* grad_tile = uniform_ptr(p.grads + tile32 * p.grad_pieces * kPieceBytes);
     auto store_grad = [&](int slot, const BPiece& v) {
 #ifndef DN_EXP_NOSAVE
-      store16_uniform(grad_tile + static_cast<long long>(slot) * kPieceBytes, pipe.lane16, v);
+      if constexpr (!S8) store16_uniform(grad_tile + static_cast<long long>(slot) * kPieceBytes, pipe.lane16, v);
+#endif
+    };
+    // S8: pieces `slot` (even) and `slot + 1` as one unit of 8 + 8 bytes per lane
+    auto store_grad_pair = [&](int slot, const BPiece& lo, const BPiece& hi) {
+#ifndef DN_EXP_NOSAVE
+      if constexpr (S8 && BF16 == 1) {
+        unsigned w[4];
+        piece_to_8bit<true>(lo, p.grad_scale, w[0], w[1]);
+        piece_to_8bit<true>(hi, p.grad_scale, w[2], w[3]);
+        store16_uniform(grad_tile + static_cast<long long>(slot >> 1) * kPieceBytes, pipe.lane16, make_uint4(w[0], w[1], w[2], w[3]));
+      }
 #endif
     };
     // Start of stage q: fetch this stage's mask word from its LDS slot, then stage what will be needed two stages on
@@ -146,6 +160,7 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
           bout[nt * P::PPT + s] = piece;
           store_grad(gslot + nt * P::PPT + s, piece);
         });
+        if constexpr (S8) store_grad_pair(gslot + nt * P::PPT, bout[nt * P::PPT], bout[nt * P::PPT + 1]);
       } else {
         f32x16 acc = acc_in;
         const unsigned words[4] = {mw.x, mw.y, mw.z, mw.w};
@@ -181,6 +196,7 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
       }
       store_grad(p.gslot_out, crgb);        // for dW(fc_rgb)
       store_grad(p.gslot_out + 1, calpha);  // for dW(fc_alpha)
+      if constexpr (S8) store_grad_pair(p.gslot_out, crgb, calpha);
       // ---- d g = fc_rgb^T d rgb, masked by relu'(layers_dir.0 out) ----
       uint4 mw = stage_begin(q++);
       auto c_rgb = [&](int, int) { return crgb; };
@@ -210,6 +226,7 @@ __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void ml
         }
       }
       store_grad(p.gslot_out, cout);  // for dW(fc_out)
+      if constexpr (S8) store_grad_pair(p.gslot_out, cout, BPiece{});
       const uint4 mw = stage_begin(q++);
       auto c_out = [&](int, int) { return cout; };
       run_stage<BF16, PT, NT, 0, 1, 0, false>(pipe, none, c_out, nullptr, [&](auto nt_c, auto, const f32x16& acc) {
@@ -274,9 +291,9 @@ __global__ void unpack_kernel(const char* __restrict__ native, int pieces_per_ti
   }
 }
 
-template <int W, int BF16>
+template <int W, int BF16, bool S8 = false>
 static int launch_backward(BwdParams p, hipStream_t stream) {
-  auto kern = mlp_backward_kernel<W, BF16>;
+  auto kern = mlp_backward_kernel<W, BF16, S8>;
   constexpr int WAVES = waves_of<BF16, 1>();
   p.n_tiles = (p.n_points + WAVES * 32 - 1) / (WAVES * 32);
   if (int rc = ensure_big_lds(reinterpret_cast<const void*>(kern))) return rc;
@@ -298,6 +315,8 @@ using namespace dn;
 
 extern "C" int dn_mlp_train_sizes(const dn_mlp_desc* desc, int precision, int64_t n_points, size_t* act_bytes,
                                   size_t* mask_bytes, size_t* grad_bytes) {
+  const bool s8 = precision == DN_PREC_BF16_S8;
+  if (s8) precision = DN_PREC_BF16;
   int rc = validate_desc(desc, precision);
   if (rc) return rc;
   DN_REQUIRE(precision != DN_PREC_F16, "training kernels exist for fp32 and bf16 (fp16 is a render-only mode)");
@@ -306,9 +325,9 @@ extern "C" int dn_mlp_train_sizes(const dn_mlp_desc* desc, int precision, int64_
   TrainLayout t;
   build_train_layout(*desc, precision, &t);
   const size_t tiles = static_cast<size_t>(padded_tiles(n_points, precision));
-  *act_bytes = tiles * t.act_pieces * kPieceBytes;
+  *act_bytes = tiles * (s8 ? (t.act_pieces + 1) / 2 : t.act_pieces) * kPieceBytes;
   *mask_bytes = tiles * t.mask_words * kPieceBytes;
-  *grad_bytes = tiles * t.grad_pieces * kPieceBytes;
+  *grad_bytes = tiles * (s8 ? (t.grad_pieces + 1) / 2 : t.grad_pieces) * kPieceBytes;
   return 0;
 }
 
@@ -340,6 +359,8 @@ extern "C" int dn_run_network_train(const dn_mlp_desc* desc, int precision, cons
                                     const float* viewdirs, const float* rays, int ray_stride, const float* z_vals,
                                     int64_t n_rays, int samples_per_ray, float* out, void* act, void* masks,
                                     dn_stream_t stream) {
+  const bool s8 = precision == DN_PREC_BF16_S8;
+  if (s8) precision = DN_PREC_BF16;
   FwdParams p;
   int rc = setup_params(desc, precision, packed, &p);
   if (rc) return rc;
@@ -362,6 +383,12 @@ extern "C" int dn_run_network_train(const dn_mlp_desc* desc, int precision, cons
   p.act = static_cast<char*>(act);
   p.masks = static_cast<char*>(masks);
   p.act_pieces = t.act_pieces; p.mask_words = t.mask_words;
+  if (s8) {
+    DN_REQUIRE(t.slot_xyz % 2 == 0 && t.slot_dir % 2 == 0 && t.slot_layer1 % 2 == 0 && t.slot_trunk0 % 2 == 0 && t.slot_feat % 2 == 0 &&
+               t.slot_dirout % 2 == 0, "dn_run_network_train (8-bit saved tensors): odd activation slot");
+    p.act_pieces = (t.act_pieces + 1) / 2;
+    p.save8 = 1;
+  }
   p.slot_xyz = t.slot_xyz; p.slot_dir = t.slot_dir; p.slot_layer1 = t.slot_layer1; p.slot_trunk0 = t.slot_trunk0;
   p.slot_feat = t.slot_feat; p.slot_dirout = t.slot_dirout;
   if (p.n_points == 0) return 0;
@@ -370,6 +397,8 @@ extern "C" int dn_run_network_train(const dn_mlp_desc* desc, int precision, cons
 
 extern "C" int dn_mlp_backward_data(const dn_mlp_desc* desc, int precision, const void* packed_bwd, const float* g_out,
                                     const void* masks, int64_t n_points, void* grads, dn_stream_t stream) {
+  const bool s8 = precision == DN_PREC_BF16_S8;
+  if (s8) precision = DN_PREC_BF16;
   int rc = validate_desc(desc, precision);
   if (rc) return rc;
   DN_REQUIRE(precision != DN_PREC_F16, "dn_mlp_backward_data: fp16 is a render-only mode");
@@ -394,6 +423,14 @@ extern "C" int dn_mlp_backward_data(const dn_mlp_desc* desc, int precision, cons
   p.gslot_dirout = t.gslot_dirout; p.gslot_feat = t.gslot_feat; p.gslot_trunk0 = t.gslot_trunk0; p.gslot_layer1 = t.gslot_layer1;
   p.gslot_out = t.gslot_out;
   const bool bf = precision == DN_PREC_BF16;
+  if (s8) {
+    DN_REQUIRE(t.gslot_dirout % 2 == 0 && t.gslot_feat % 2 == 0 && t.gslot_trunk0 % 2 == 0 && t.gslot_layer1 % 2 == 0 && t.gslot_out % 2 == 0,
+               "dn_mlp_backward_data (8-bit saved tensors): odd gradient slot");
+    p.grad_pieces = (t.grad_pieces + 1) / 2;
+    p.grad_scale = g_s8_grad_scale;
+    if (desc->hidden_size == 256) return launch_backward<256, 1, true>(p, as_stream(stream));
+    if (desc->hidden_size == 128) return launch_backward<128, 1, true>(p, as_stream(stream));
+  }
   if (desc->hidden_size == 256) return bf ? launch_backward<256, true>(p, as_stream(stream)) : launch_backward<256, false>(p, as_stream(stream));
   if (desc->hidden_size == 128) return bf ? launch_backward<128, true>(p, as_stream(stream)) : launch_backward<128, false>(p, as_stream(stream));
   set_error("dn_mlp_backward_data: no kernel instance for W=%d", desc->hidden_size);
@@ -462,6 +499,11 @@ struct WgParams {
   int ldw, col_pe0;
   float* db;
   int shape;                      // index into the instantiation table (wg_shape_index)
+  // 8-bit saved tensors (DN_PREC_BF16_S8): slots / strides above count 1 KiB UNITS (= two 8-byte-per-lane pieces side by
+  // side); dy_odd = which half of its unit a custom dY piece is; out_scale = 1 / (the power of two the gradients were
+  // multiplied by before they were rounded to e5m2)
+  int dy_odd;
+  float out_scale;
 };
 
 constexpr int kWgLdsBytes = 144 * 1024;
@@ -470,8 +512,7 @@ constexpr int kWgLdsBytes = 144 * 1024;
 // an iteration is amortised over 2 or 4 of them (the as-shipped 4x128 nets are all "small").
 constexpr int wg_tiles_per_iter(int pieces) { return pieces <= 12 ? 4 : (pieces <= 24 ? 2 : 1); }
 
-constexpr int wg_stages_for(int pieces) {
-  const int tpi = wg_tiles_per_iter(pieces);
+constexpr int wg_stages_for(int pieces, int tpi) {
   int s = kWgLdsBytes / (pieces * kPieceBytes);
   if (s > 16) s = 16;
   const int per_wave = (pieces + 7) / 8;
@@ -481,19 +522,21 @@ constexpr int wg_stages_for(int pieces) {
 
 // NTN: 32-row tiles of the output (dY) width; XT: 32-column tiles of the hidden input; PET: 32-column tiles of the
 // appended positional encoding; CUSTOM: dY is the single custom output-gradient piece (fc_rgb / fc_alpha / fc_out)
-template <int NTN_, int XT_, int PET_, bool CUSTOM_>
+template <int NTN_, int XT_, int PET_, bool CUSTOM_, bool S8_ = false>
 struct WgShape {
   static constexpr int NTN = NTN_, XT = XT_, PET = PET_;
   static constexpr bool CUSTOM = CUSTOM_;
+  static constexpr bool S8 = S8_;                          // 8-bit saved tensors: a staged 1 KiB unit holds BOTH pieces of a 32-feature tile
   static constexpr int KT = XT + PET + 1;                  // k-tiles incl. the all-ones (bias) tile
   static constexpr int KGROUPS = 8 / NTN;                  // waves sharing one n-tile split the k-tiles
   static constexpr int J = (KT + KGROUPS - 1) / KGROUPS;   // k-tiles (accumulators) per wave
-  static constexpr int N_DY = CUSTOM ? 1 : 2 * NTN;
-  static constexpr int N_X = 2 * XT, N_PE = 2 * PET;
+  static constexpr int UPT = S8 ? 1 : 2;                   // staged 1 KiB units per 32-feature tile
+  static constexpr int N_DY = CUSTOM ? 1 : UPT * NTN;
+  static constexpr int N_X = UPT * XT, N_PE = UPT * PET;
   static constexpr int PIECES = N_DY + N_X + N_PE;         // 1 KiB pieces staged per 32-point tile
   static constexpr int PER_WAVE = (PIECES + 7) / 8;        // DMAs per tile of the busiest wave
-  static constexpr int TPI = wg_tiles_per_iter(PIECES);     // tiles per barrier
-  static constexpr int STAGES = wg_stages_for(PIECES);      // tile buffers in LDS; STAGES - TPI tiles in flight
+  static constexpr int TPI = wg_tiles_per_iter(S8 ? 2 * PIECES : PIECES);   // tiles per barrier: by the MFMA count of a tile, not by its bytes
+  static constexpr int STAGES = wg_stages_for(PIECES, TPI); // tile buffers in LDS; STAGES - TPI tiles in flight
   static_assert(STAGES >= 2 * TPI && STAGES * PIECES * kPieceBytes <= 160 * 1024, "LDS budget");
   static_assert(XT + PET >= 1 && NTN * KGROUPS == 8, "shape");
 };
@@ -511,6 +554,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* piece_lane /* piece base +
   v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
   v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
   return __builtin_bit_cast(bf16x8, v);
+}
+
+// 8-bit form (ds_read_b64_tr_b8; lane / byte mapping measured: profiles/r02_tr8_probe.md): a 16-lane group reads an
+// 8-row x 16-byte block - lane li supplies the address of the 8-byte chunk (row li >> 1, half li & 1) - and receives byte
+// column li, 8 rows.  Rows = points, byte columns = the 16 features of one piece (half h = the native piece's lane half):
+// ONE read is the 8-point operand block of v_mfma_f32_32x32x16_bf8_fp8 (the 16-bit form needs two).
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ long tr8_frag(const char* unit_lane /* unit base + odd * 8 + this lane's chunk offset */, int point0) {
+  const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(unit_lane + point0 * 16));
+  return __builtin_bit_cast(long, v);
 }
 
 // feature index (within a 32-feature tile) that transposed fragment row/column `i` (0..31) refers to
@@ -544,7 +597,8 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
   // receives feature column li; group g covers feature sub-block fs = g&1 and k-half hh = g>>1 of the MFMA operand
   const int li = lane & 15, grp = lane >> 4;
   const int fs = grp & 1, hh = grp >> 1;
-  const int lane_off = ((((li & 3) >> 1) * 32 + (li >> 2) + 8 * hh) * 16) + ((li & 3) & 1) * 8;
+  const int lane_off = S::S8 ? (((li & 1) * 32 + (li >> 1) + 8 * hh) * 16)
+                             : ((((li & 3) >> 1) * 32 + (li >> 2) + 8 * hh) * 16) + ((li & 3) & 1) * 8;
 
   // ---- staging: each 1 KiB piece is one LDS-DMA (opaque asm: the counted waits below are ours; hipcc would drain
   // with vmcnt(0) at every barrier).  This wave stages pieces wave, wave + 8, ... of every tile.
@@ -607,7 +661,7 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
   for (int e = 0; e < 8; ++e) { ones[e] = static_cast<__bf16>(1.0f); zeros[e] = static_cast<__bf16>(0.0f); }
 
   // one staged tile: A = dY^T fragments of this wave's n-tile, B = the X / PE / all-ones k-tiles, 2 MFMAs per k-tile
-  auto consume = [&](long long tile, int cb) {
+  auto consume_16 = [&](long long tile, int cb) {
     const char* base = smem + cb * BUF + lane_off;
     // A = dY^T fragments of this wave's n-tile, two 16-point k-steps
     // (a custom dY has a single piece: the fs=1 lane groups re-read it and are zeroed)
@@ -653,6 +707,54 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
     });
+  };
+  auto consume_s8 = [&](long long tile, int cb) {
+    const char* base = smem + cb * BUF + lane_off;
+    constexpr long kOnes = 0x3838383838383838L;   // 1.0 in e4m3, eight times
+    // A = dY^T (e5m2): unit `ntile` holds both pieces of the n-tile, fs picks the half; a custom dY is half dy_odd of its unit
+    const char* dy = base + (S::CUSTOM ? p.dy_odd * 8 : ntile * kPieceBytes + fs * 8);
+    long a0 = tr8_frag(dy, 0);
+    long a1 = tr8_frag(dy, 16);
+    if constexpr (S::CUSTOM) {
+      a0 = fs ? 0L : a0;
+      a1 = fs ? 0L : a1;
+    }
+    const long long valid = p.n_points - tile * 32;  // points of this tile that exist (the rest are padding copies)
+    if (valid < 32) {
+      auto keep = [&](int first) -> long {   // bytes of the points first .. first+7 that exist
+        const long long n = valid - first;
+        return n >= 8 ? -1L : (n <= 0 ? 0L : static_cast<long>((1ull << (8 * n)) - 1ull));
+      };
+      a0 &= keep(8 * hh);
+      a1 &= keep(16 + 8 * hh);
+    }
+    static_for<S::J>([&](auto j_c) {
+      constexpr int j = decltype(j_c)::value;
+      long b0, b1;
+      if constexpr (S::KGROUPS == 1) {
+        if constexpr (j == S::KT - 1) { b0 = kOnes; b1 = kOnes; }
+        else {
+          const char* pb = base + (S::N_DY + j) * kPieceBytes + fs * 8;
+          b0 = tr8_frag(pb, 0);
+          b1 = tr8_frag(pb, 16);
+        }
+      } else {
+        const int kt = kgroup + j * S::KGROUPS;           // wave-uniform; kt >= KT: an unused accumulator
+        const int ktr = kt < S::KT - 1 ? kt : S::KT - 2;  // a unit that exists
+        const char* pb = base + (S::N_DY + ktr) * kPieceBytes + fs * 8;
+        b0 = tr8_frag(pb, 0);
+        b1 = tr8_frag(pb, 16);
+        const bool is_ones = kt >= S::KT - 1;
+        b0 = is_ones ? kOnes : b0;
+        b1 = is_ones ? kOnes : b1;
+      }
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a0, b0, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a1, b1, acc[j], 0, 0, 0);
+    });
+  };
+  auto consume = [&](long long tile, int cb) {
+    if constexpr (S::S8) consume_s8(tile, cb);
+    else consume_16(tile, cb);
   };
   // tile k of this workgroup's sequence (k = 0, 1, ...) is 32-point tile wg + k * n_wg and lives in buffer k % STAGES
   int buf = 0;
@@ -727,8 +829,9 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
 #if DN_WG_EPI == 1
         if (col >= 0 && acc[j][r] == 1.2345f) p.dW[static_cast<long long>(n) * p.ldw + col] = 1.0f;
 #else
-        if (col >= 0) atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col, acc[j][r]);
-        else if (col == -2 && p.db != nullptr) atomicAdd(p.db + n, acc[j][r]);
+        const float val = S::S8 ? acc[j][r] * p.out_scale : acc[j][r];
+        if (col >= 0) atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col, val);
+        else if (col == -2 && p.db != nullptr) atomicAdd(p.db + n, val);
 #endif
       }
     }
@@ -896,8 +999,9 @@ __device__ __forceinline__ void weight_grad_unit_f32(const WgParams& p, int wg, 
           n = acc_row(r, half);
           if (n >= p.custom_rows) continue;
         }
-        if (col >= 0) atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col, acc[j][r]);
-        else if (col == -2 && p.db != nullptr) atomicAdd(p.db + n, acc[j][r]);
+        const float val = acc[j][r];
+        if (col >= 0) atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col, val);
+        else if (col == -2 && p.db != nullptr) atomicAdd(p.db + n, val);
       }
     }
   });
@@ -941,6 +1045,21 @@ __device__ __forceinline__ void weight_grad_dispatch(const WgParams& p, int wg, 
   }
 }
 
+__device__ __forceinline__ void weight_grad_dispatch_s8(const WgParams& p, int wg, int n_wg, char* smem) {
+  switch (p.shape) {
+#define X(id, a, b, c, d) case id: weight_grad_unit<WgShape<a, b, c, d, true>>(p, wg, n_wg, smem); break;
+    DN_WG_SHAPES(X)
+#undef X
+    default: break;
+  }
+}
+static int wg_shape_pieces_s8(int shape) {
+#define X(id, a, b, c, d) if (shape == id) return WgShape<a, b, c, d, true>::PIECES;
+  DN_WG_SHAPES(X)
+#undef X
+  return 0;
+}
+
 __device__ __forceinline__ void weight_grad_dispatch_f32(const WgParams& p, int wg, int n_wg, char* smem) {
   switch (p.shape) {
 #define X(id, a, b, c, d) case id: weight_grad_unit_f32<WgShape32<a, b, c, d>>(p, wg, n_wg, smem); break;
@@ -979,6 +1098,14 @@ __global__ __launch_bounds__(512, 2) void weight_grad_batch_kernel(WgBatch b) {
   weight_grad_dispatch(p, static_cast<int>(blockIdx.x) - b.wg_begin[u], b.wg_begin[u + 1] - b.wg_begin[u], smem);
 }
 
+__global__ __launch_bounds__(512, 2) void weight_grad_batch_kernel_s8(WgBatch b) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int u = 0;
+  while (u + 1 < b.n_units && static_cast<int>(blockIdx.x) >= b.wg_begin[u + 1]) ++u;
+  const WgParams p = b.u[u];
+  weight_grad_dispatch_s8(p, static_cast<int>(blockIdx.x) - b.wg_begin[u], b.wg_begin[u + 1] - b.wg_begin[u], smem);
+}
+
 __global__ __launch_bounds__(512, 2) void weight_grad_batch_kernel_f32(WgBatch b) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int u = 0;
@@ -988,7 +1115,8 @@ __global__ __launch_bounds__(512, 2) void weight_grad_batch_kernel_f32(WgBatch b
 }
 
 static int wg_fill(const dn_mlp_desc* desc, const TrainLayout& t, const void* act, const void* grads, int64_t n_points,
-                   int g_slot, int n_out, int x_slot, int x_width, int pe_kind, float* dW, int ldw, float* db, WgParams* out) {
+                   int g_slot, int n_out, int x_slot, int x_width, int pe_kind, float* dW, int ldw, float* db, WgParams* out,
+                   bool s8 = false) {
   const int custom_rows = (n_out < 32) ? n_out : 0;  // fc_rgb (3) / fc_alpha (1) / fc_out (4): one custom dY piece
   if (custom_rows) n_out = 32;
   DN_REQUIRE(n_out % 32 == 0 && x_width % 32 == 0 && pe_kind >= 0 && pe_kind <= 2, "weight_grad: bad layer shape");
@@ -1008,6 +1136,16 @@ static int wg_fill(const dn_mlp_desc* desc, const TrainLayout& t, const void* ac
     set_error("weight_grad: no kernel instance for a %d x (%d + %d) layer%s", n_out, x_width, 32 * pe_tiles, custom_rows ? " (custom dY)" : "");
     return DN_E_UNSUPPORTED;
   }
+  if (s8) {
+    // 8-bit buffers: two pieces side by side per 1 KiB unit - every slot / stride in units; all piece slots of a layer are even
+    // except a custom dY piece (fc_rgb: even half, fc_alpha: odd half of the last unit)
+    DN_REQUIRE(custom_rows || (p.g_slot % 2) == 0, "weight_grad (8-bit buffers): odd gradient slot");
+    DN_REQUIRE((p.x_slot % 2) == 0 && (p.pe_slot % 2) == 0, "weight_grad (8-bit buffers): odd activation slot");
+    p.dy_odd = p.g_slot & 1;
+    p.g_slot /= 2; p.x_slot /= 2; p.pe_slot /= 2;
+    p.act_pieces = (t.act_pieces + 1) / 2; p.grad_pieces = (t.grad_pieces + 1) / 2;
+    p.out_scale = 1.0f / g_s8_grad_scale;
+  }
   *out = p;
   return 0;
 }
@@ -1015,10 +1153,54 @@ static int wg_fill(const dn_mlp_desc* desc, const TrainLayout& t, const void* ac
 template <class K>
 static int wg_attr(K kern) { return ensure_big_lds(reinterpret_cast<const void*>(kern)); }
 
+// bf16 native pieces -> 8-bit units (two pieces side by side): e4m3 for activations (WHICH = 0), e5m2 times `scale` for
+// gradients (WHICH = 1).  Test scaffolding for the 8-bit weight-gradient kernel and the reference of what the training kernels
+// store directly in DN_PREC_BF16_S8.
+template <int WHICH>
+__global__ void convert_s8_kernel(const char* __restrict__ native, long long n_tiles, int pieces, float scale, char* __restrict__ out) {
+  const int units = (pieces + 1) / 2;
+  const long long total = n_tiles * units * 64;
+  for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+       idx += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int lane = static_cast<int>(idx % 64);
+    const long long tu = idx / 64;
+    const int unit = static_cast<int>(tu % units);
+    const long long tile = tu / units;
+    int words[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int piece = 2 * unit + half;
+      if (piece >= pieces) continue;
+      const __bf16* src = reinterpret_cast<const __bf16*>(native + ((tile * pieces + piece) * 64 + lane) * 16);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = static_cast<float>(src[e]) * scale;
+        if constexpr (WHICH == 1) v[e] = fminf(fmaxf(v[e], -57344.0f), 57344.0f);   // e5m2 has infinities: saturate instead
+      }
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        int w = 0;
+        if constexpr (WHICH == 0) {
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * d], v[4 * d + 1], w, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * d + 2], v[4 * d + 3], w, true);
+        } else {
+          w = __builtin_amdgcn_cvt_pk_bf8_f32(v[4 * d], v[4 * d + 1], w, false);
+          w = __builtin_amdgcn_cvt_pk_bf8_f32(v[4 * d + 2], v[4 * d + 3], w, true);
+        }
+        words[half * 2 + d] = w;
+      }
+    }
+    *reinterpret_cast<int4*>(out + ((tile * units + unit) * 64 + lane) * 16) = make_int4(words[0], words[1], words[2], words[3]);
+  }
+}
+
 }  // namespace dn
 
 extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, const void* act, const void* grads,
                                       int64_t n_points, float* const* h_dW, float* const* h_db, dn_stream_t stream) {
+  const bool s8 = precision == DN_PREC_BF16_S8;
+  if (s8) precision = DN_PREC_BF16;   // same layouts and slots, half-size pieces
   int rc = validate_desc(desc, precision);
   if (rc) return rc;
   DN_REQUIRE(precision == DN_PREC_BF16 || precision == DN_PREC_F32, "dn_mlp_weight_grad_all: bf16 or fp32 buffers (fp16 is a render-only mode)");
@@ -1039,27 +1221,27 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
   b.n_units = n_units;
   // parameter order: layer1, layers_xyz[0..D-2], then layers_dir.0, fc_alpha, fc_rgb, fc_feat | fc_out (models.py:207-229)
   int u = 0;
-  if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_layer1, W, 0, 0, 1, h_dW[u], dim_xyz, h_db[u], &b.u[u]))) return rc;
+  if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_layer1, W, 0, 0, 1, h_dW[u], dim_xyz, h_db[u], &b.u[u], s8))) return rc;
   ++u;
   int x_slot = t.slot_layer1;
   for (int i = 0; i + 1 < D; ++i, ++u) {
     const bool skip = (L.skip_mask >> i) & 1u;
     if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_trunk0 + i * t.kh, W, x_slot, W, skip ? 1 : 0, h_dW[u],
-                      W + (skip ? dim_xyz : 0), h_db[u], &b.u[u])))
+                      W + (skip ? dim_xyz : 0), h_db[u], &b.u[u], s8)))
       return rc;
     x_slot = t.slot_trunk0 + i * t.kh;
   }
   if (desc->use_viewdirs) {
-    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_dirout, W / 2, t.slot_feat, W, 2, h_dW[u], W + dim_dir, h_db[u], &b.u[u]))) return rc;
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_dirout, W / 2, t.slot_feat, W, 2, h_dW[u], W + dim_dir, h_db[u], &b.u[u], s8))) return rc;
     ++u;
-    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out + 1, 1, x_slot, W, 0, h_dW[u], W, h_db[u], &b.u[u]))) return rc;
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out + 1, 1, x_slot, W, 0, h_dW[u], W, h_db[u], &b.u[u], s8))) return rc;
     ++u;
-    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out, 3, t.slot_dirout, W / 2, 0, h_dW[u], W / 2, h_db[u], &b.u[u]))) return rc;
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out, 3, t.slot_dirout, W / 2, 0, h_dW[u], W / 2, h_db[u], &b.u[u], s8))) return rc;
     ++u;
-    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_feat, W, x_slot, W, 0, h_dW[u], W, h_db[u], &b.u[u]))) return rc;
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_feat, W, x_slot, W, 0, h_dW[u], W, h_db[u], &b.u[u], s8))) return rc;
     ++u;
   } else {
-    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out, 4, x_slot, W, 0, h_dW[u], W, h_db[u], &b.u[u]))) return rc;
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out, 4, x_slot, W, 0, h_dW[u], W, h_db[u], &b.u[u], s8))) return rc;
     ++u;
   }
   // divide the workgroups (one per CU) among the units in proportion to the pieces each streams (largest remainder)
@@ -1068,7 +1250,7 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
   if (total_wg < n_units) total_wg = n_units;
   long long cost[kWgMaxUnits], cost_sum = 0;
   for (int i = 0; i < n_units; ++i) {
-    cost[i] = f32 ? wg_shape_pieces_f32(b.u[i].shape) : wg_shape_pieces(b.u[i].shape);
+    cost[i] = f32 ? wg_shape_pieces_f32(b.u[i].shape) : (s8 ? wg_shape_pieces_s8(b.u[i].shape) : wg_shape_pieces(b.u[i].shape));
     cost_sum += cost[i];
   }
   int share[kWgMaxUnits], given = 0;
@@ -1089,8 +1271,11 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
     if (share[i] > tiles) share[i] = static_cast<int>(tiles);  // idle workgroups would exit at once anyway
     b.wg_begin[i + 1] = b.wg_begin[i] + share[i];
   }
-  if ((rc = f32 ? wg_attr(weight_grad_batch_kernel_f32) : wg_attr(weight_grad_batch_kernel))) return rc;
-  if (f32)
+  if ((rc = f32 ? wg_attr(weight_grad_batch_kernel_f32) : (s8 ? wg_attr(weight_grad_batch_kernel_s8) : wg_attr(weight_grad_batch_kernel)))) return rc;
+  if (s8)
+    hipLaunchKernelGGL(weight_grad_batch_kernel_s8, dim3(static_cast<unsigned>(b.wg_begin[n_units])), dim3(512), kWgLdsBytes,
+                       as_stream(stream), b);
+  else if (f32)
     hipLaunchKernelGGL(weight_grad_batch_kernel_f32, dim3(static_cast<unsigned>(b.wg_begin[n_units])), dim3(512), 158 * 1024,
                        as_stream(stream), b);
   else
@@ -1117,4 +1302,28 @@ extern "C" int dn_mlp_weight_grad(const dn_mlp_desc* desc, int precision, const 
   const long long grid = tiles < cus ? tiles : cus;
   hipLaunchKernelGGL(weight_grad_kernel, dim3(static_cast<unsigned>(grid)), dim3(512), wg_shape_lds(p.shape), as_stream(stream), p);
   return check_launch("dn_mlp_weight_grad");
+}
+
+extern "C" int dn_set_s8_grad_scale(float scale) {
+  DN_REQUIRE(scale > 0.0f, "dn_set_s8_grad_scale: the scale must be positive");
+  g_s8_grad_scale = scale;
+  return 0;
+}
+
+extern "C" int dn_mlp_convert_saved_s8(const dn_mlp_desc* desc, int which, const void* native_bf16, int64_t n_points, void* out_s8,
+                                       dn_stream_t stream) {
+  int rc = validate_desc(desc, DN_PREC_BF16);
+  if (rc) return rc;
+  DN_REQUIRE((which == 0 || which == 1) && native_bf16 && out_s8 && n_points >= 0, "dn_mlp_convert_saved_s8: bad arguments");
+  if (n_points == 0) return 0;
+  TrainLayout t;
+  build_train_layout(*desc, DN_PREC_BF16, &t);
+  const long long tiles = padded_tiles(n_points, DN_PREC_BF16);
+  if (which == 0)
+    hipLaunchKernelGGL(convert_s8_kernel<0>, dim3(2048), dim3(256), 0, as_stream(stream), static_cast<const char*>(native_bf16), tiles,
+                       t.act_pieces, 1.0f, static_cast<char*>(out_s8));
+  else
+    hipLaunchKernelGGL(convert_s8_kernel<1>, dim3(2048), dim3(256), 0, as_stream(stream), static_cast<const char*>(native_bf16), tiles,
+                       t.grad_pieces, g_s8_grad_scale, static_cast<char*>(out_s8));
+  return check_launch("dn_mlp_convert_saved_s8");
 }

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("DEXNERF_HIP_LIB", os.path.join(os.path.dirname(_HERE)
 PREC_F32 = 0
 PREC_BF16 = 1
 PREC_F16 = 2
+PREC_BF16_S8 = 3   # training entry points: bf16 arithmetic, 8-bit saved activations / gradients (experimental)
 
 EXPORTS = (
     "dn_abi_version", "dn_last_error", "dn_ray_bundle", "dn_coarse_depths", "dn_positional_encoding",
@@ -25,6 +26,7 @@ EXPORTS = (
     "dn_mlp_backward_data", "dn_mlp_unpack", "dn_mlp_weight_grad", "dn_mlp_weight_grad_all",
     "dn_select_rays", "dn_select_rays_indirect", "dn_ndc_rays", "dn_dex_error_sweep", "dn_depth_error_image",
     "dn_render_train_workspace_bytes", "dn_render_rays_train", "dn_render_rays_backward",
+    "dn_set_s8_grad_scale", "dn_mlp_convert_saved_s8",
 )
 
 
@@ -78,6 +80,8 @@ def _declare(lib):
     lib.dn_dex_error_sweep.argtypes = [fp, fp, c_int, c_int64, vp, c_float, c_float, vp, vp]
     lib.dn_depth_error_image.argtypes = [fp, fp, vp, c_int, c_int, c_float, fp, vp]
     lib.dn_mlp_weight_grad_all.argtypes = [POINTER(MlpDesc), c_int, vp, vp, c_int64, POINTER(c_void_p), POINTER(c_void_p), vp]
+    lib.dn_set_s8_grad_scale.argtypes = [c_float]
+    lib.dn_mlp_convert_saved_s8.argtypes = [POINTER(MlpDesc), c_int, vp, c_int64, vp, vp]
     lib.dn_render_train_workspace_bytes.argtypes = [c_int64, c_int, c_int]
     lib.dn_render_train_workspace_bytes.restype = c_size_t
     lib.dn_render_rays_train.argtypes = [POINTER(MlpDesc), vp, POINTER(MlpDesc), vp, c_int, fp, c_int, c_int64, c_int, c_int,

@@ -12,19 +12,37 @@ from . import _hip
 from ._hip import MlpDesc, check, f32c, host_floats, lib, ptr, stream
 
 _precision = _hip.PREC_F32
+_save8 = False   # bf16 training keeps its saved activations / gradients at 8 bits (set_precision("bf16-s8"))
 
 
 def set_precision(name):
-    """'fp32' (exact fp32 MFMA chains, the parity mode), 'bf16' (bf16 MFMA, fp32 accumulate; render + training) or
+    """'fp32' (exact fp32 MFMA chains, the parity mode), 'bf16' (bf16 MFMA, fp32 accumulate; render + training),
     'fp16' (fp16 MFMA at bf16's rate with a 10-bit mantissa: ~57 dB instead of ~42 dB against fp32; render only -
-    training in this mode differentiates the nn.Linear composition)."""
-    global _precision
+    training in this mode differentiates the nn.Linear composition) or 'bf16-s8' (bf16 in every kernel; the TRAINING step
+    stores what it saves for the backward - activations as e4m3, layer gradients as e5m2 x a power-of-two scale - at 8 bits and
+    forms the weight gradients with the fp8 MFMA: half the saved-tensor traffic.  Rendering is the bf16 mode's, bit for bit)."""
+    global _precision, _save8
+    name = str(name).lower()
+    _save8 = name in ("bf16-s8", "bf16_s8")
     _precision = {"fp32": _hip.PREC_F32, "f32": _hip.PREC_F32, "bf16": _hip.PREC_BF16, "fp16": _hip.PREC_F16,
-                  "f16": _hip.PREC_F16}[str(name).lower()]
+                  "f16": _hip.PREC_F16, "bf16-s8": _hip.PREC_BF16, "bf16_s8": _hip.PREC_BF16}[name]
 
 
 def get_precision():
+    if _save8 and _precision == _hip.PREC_BF16:
+        return "bf16-s8"
     return {_hip.PREC_F32: "fp32", _hip.PREC_BF16: "bf16", _hip.PREC_F16: "fp16"}[_precision]
+
+
+def train_precision(packed):
+    """The precision code the TRAINING entry points get for this packed network (DN_PREC_BF16_S8 in the 'bf16-s8' mode).  A
+    forward records it with what it saves; the backward of those buffers uses the recorded code."""
+    return _hip.PREC_BF16_S8 if (_save8 and packed.precision == _hip.PREC_BF16) else packed.precision
+
+
+def set_s8_grad_scale(scale):
+    """Power of two the saved layer gradients are multiplied by before they are rounded to e5m2 (default 65536)."""
+    check(lib().dn_set_s8_grad_scale(float(scale)), "dn_set_s8_grad_scale")
 
 
 def _row_view(t):
@@ -163,14 +181,27 @@ def pack_backward(packed, weights):
     packed._keep_bwd = ws
 
 
-def train_sizes(packed, n_points):
+def train_sizes(packed, n_points, s8=False, prec=None):
     a, m, g = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
-    check(lib().dn_mlp_train_sizes(ctypes.byref(packed.desc), packed.precision, n_points, ctypes.byref(a), ctypes.byref(m),
+    if prec is None:
+        prec = _hip.PREC_BF16_S8 if s8 else packed.precision
+    check(lib().dn_mlp_train_sizes(ctypes.byref(packed.desc), prec, n_points, ctypes.byref(a), ctypes.byref(m),
                                    ctypes.byref(g)), "dn_mlp_train_sizes")
     return a.value, m.value, g.value
 
 
-def run_network_train(packed, pts, viewdirs, samples_per_ray, rays=None, z_vals=None):
+def convert_saved_s8(packed, which, native, n_points, grad_scale=None):
+    """bf16 saved activations (which = 0) / gradients (which = 1) -> the 8-bit unit layout of DN_PREC_BF16_S8 (experimental)."""
+    a8, _, g8 = train_sizes(packed, n_points, s8=True)
+    out = torch.empty(a8 if which == 0 else g8, dtype=torch.uint8, device=native.device)
+    if grad_scale is not None:
+        check(lib().dn_set_s8_grad_scale(float(grad_scale)), "dn_set_s8_grad_scale")
+    check(lib().dn_mlp_convert_saved_s8(ctypes.byref(packed.desc), which, ptr(native), n_points, ptr(out), stream()),
+          "dn_mlp_convert_saved_s8")
+    return out
+
+
+def run_network_train(packed, pts, viewdirs, samples_per_ray, rays=None, z_vals=None, prec=None):
     """Training forward: raw radiance field + the opaque (act, masks) buffers the backward needs.  Either explicit
     points (+ per-ray view directions) or packed ray rows + depths (the points are formed in the kernel)."""
     if rays is not None:
@@ -183,27 +214,29 @@ def run_network_train(packed, pts, viewdirs, samples_per_ray, rays=None, z_vals=
         n_pts = pts.shape[0]
         assert n_pts % samples_per_ray == 0
         dev = pts.device
-    a_bytes, m_bytes, _ = train_sizes(packed, n_pts)
+    prec = packed.precision if prec is None else prec
+    a_bytes, m_bytes, _ = train_sizes(packed, n_pts, prec=prec)
     out = torch.empty((n_pts, 4), dtype=torch.float32, device=dev)
     act = torch.empty(a_bytes, dtype=torch.uint8, device=dev)
     masks = torch.empty(m_bytes, dtype=torch.uint8, device=dev)
     if rays is not None:
-        check(lib().dn_run_network_train(ctypes.byref(packed.desc), packed.precision, ptr(packed.buffer), None, None, ptr(rays),
+        check(lib().dn_run_network_train(ctypes.byref(packed.desc), prec, ptr(packed.buffer), None, None, ptr(rays),
                                          rays.shape[1], ptr(z_vals), n_pts // samples_per_ray, samples_per_ray, ptr(out),
                                          ptr(act), ptr(masks), stream()), "dn_run_network_train")
         return out, act, masks
     vd = None if viewdirs is None else f32c(viewdirs).reshape(-1, 3)
-    check(lib().dn_run_network_train(ctypes.byref(packed.desc), packed.precision, ptr(packed.buffer), ptr(pts), ptr(vd), None,
+    check(lib().dn_run_network_train(ctypes.byref(packed.desc), prec, ptr(packed.buffer), ptr(pts), ptr(vd), None,
                                      0, None, n_pts // samples_per_ray, samples_per_ray, ptr(out), ptr(act), ptr(masks),
                                      stream()), "dn_run_network_train")
     return out, act, masks
 
 
-def mlp_backward_data(packed, g_out, masks, n_points):
+def mlp_backward_data(packed, g_out, masks, n_points, prec=None):
     g_out = f32c(g_out).reshape(-1, 4)
-    _, _, g_bytes = train_sizes(packed, n_points)
+    prec = packed.precision if prec is None else prec
+    _, _, g_bytes = train_sizes(packed, n_points, prec=prec)
     grads = torch.empty(g_bytes, dtype=torch.uint8, device=g_out.device)
-    check(lib().dn_mlp_backward_data(ctypes.byref(packed.desc), packed.precision, ptr(packed.buffer_bwd), ptr(g_out),
+    check(lib().dn_mlp_backward_data(ctypes.byref(packed.desc), prec, ptr(packed.buffer_bwd), ptr(g_out),
                                      ptr(masks), n_points, ptr(grads), stream()), "dn_mlp_backward_data")
     return grads
 
@@ -221,9 +254,9 @@ def mlp_weight_grad(packed, act, grads, n_points, g_slot, n_out, x_slot, x_width
                                    x_slot, x_width, pe_kind, ptr(d_w), d_w.shape[1], ptr(d_b), stream()), "dn_mlp_weight_grad")
 
 
-def mlp_weight_grad_all(packed, act, grads, n_points, shapes):
+def mlp_weight_grad_all(packed, act, grads, n_points, shapes, s8=False, prec=None):
     """bf16 buffers: every layer's (dW, db) in one launch.  `shapes` = [(out, in)] in linear_modules() order; returns
-    [(dW, db)] as views of ONE zero-filled fp32 buffer."""
+    [(dW, db)] as views of ONE zero-filled fp32 buffer.  s8: the buffers are in the 8-bit unit layout (convert_saved_s8)."""
     dev = act.device
     total = sum(o * i + o for o, i in shapes)
     flat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -234,18 +267,20 @@ def mlp_weight_grad_all(packed, act, grads, n_points, shapes):
         out.append((d_w, d_b))
     wp = (c_void_p * len(out))(*[w.data_ptr() for w, _ in out])
     bp = (c_void_p * len(out))(*[b.data_ptr() for _, b in out])
-    check(lib().dn_mlp_weight_grad_all(ctypes.byref(packed.desc), packed.precision, ptr(act), ptr(grads), n_points, wp, bp,
-                                       stream()), "dn_mlp_weight_grad_all")
+    if prec is None:
+        prec = _hip.PREC_BF16_S8 if s8 else packed.precision
+    check(lib().dn_mlp_weight_grad_all(ctypes.byref(packed.desc), prec, ptr(act), ptr(grads), n_points, wp, bp, stream()),
+          "dn_mlp_weight_grad_all")
     return out
 
 
-def mlp_weight_grad_all_into(packed, act, grads, n_points, views):
+def mlp_weight_grad_all_into(packed, act, grads, n_points, views, prec=None):
     """The same launch accumulating into caller-owned (dW, db) tensors (dense fp32 with the nn.Linear shapes, e.g. the
     `.grad` views of a parallel.FlatGradBucket, already zeroed for this step)."""
     wp = (c_void_p * len(views))(*[w.data_ptr() for w, _ in views])
     bp = (c_void_p * len(views))(*[b.data_ptr() for _, b in views])
-    check(lib().dn_mlp_weight_grad_all(ctypes.byref(packed.desc), packed.precision, ptr(act), ptr(grads), n_points, wp, bp,
-                                       stream()), "dn_mlp_weight_grad_all")
+    check(lib().dn_mlp_weight_grad_all(ctypes.byref(packed.desc), packed.precision if prec is None else prec, ptr(act), ptr(grads),
+                                       n_points, wp, bp, stream()), "dn_mlp_weight_grad_all")
 
 
 def run_network_pts(packed, pts, viewdirs, samples_per_ray):
@@ -416,8 +451,10 @@ def render_rays_train(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, n
     def new(*shape):
         return torch.empty(shape, dtype=torch.float32, device=dev)
 
+    prec = train_precision(packed_c)
+
     def bufs(packed, n_points):
-        a, m, _ = train_sizes(packed, n_points)
+        a, m, _ = train_sizes(packed, n_points, prec=prec)
         return torch.empty(a, dtype=torch.uint8, device=dev), torch.empty(m, dtype=torch.uint8, device=dev)
     act_c, masks_c = bufs(packed_c, n * num_coarse)
     act_f, masks_f = bufs(packed_f, n * (num_coarse + nf)) if fine else (None, None)
@@ -427,13 +464,13 @@ def render_rays_train(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, n
     t = {name: (None if draws.get(name) is None else f32c(draws[name])) for name in ("t_rand", "noise_c", "u", "noise_f")}
     check(lib().dn_render_rays_train(
         ctypes.byref(packed_c.desc), ptr(packed_c.buffer),
-        ctypes.byref(packed_f.desc) if fine else None, ptr(packed_f.buffer) if fine else None, packed_c.precision,
+        ctypes.byref(packed_f.desc) if fine else None, ptr(packed_f.buffer) if fine else None, prec,
         ptr(rays), rays.shape[1], n, num_coarse, nf, int(bool(lindisp)), float(noise_std), int(bool(white)),
         host_floats(m_thres), k, ptr(t["t_rand"]), ptr(t["noise_c"]), ptr(t["u"]), ptr(t["noise_f"]),
         ptr(rgb_c), ptr(depth_c), ptr(acc_c), ptr(rgb_f), ptr(depth_f), ptr(acc_f), ptr(dex), ptr(ws),
         ptr(act_c), ptr(masks_c), ptr(act_f), ptr(masks_f), stream()), "dn_render_rays_train")
     saved = dict(rays=rays, ws=ws, act_c=act_c, masks_c=masks_c, act_f=act_f, masks_f=masks_f, noise_c=t["noise_c"],
-                 noise_f=t["noise_f"], n=n, nc=num_coarse, nf=nf, noise_std=float(noise_std), white=bool(white))
+                 noise_f=t["noise_f"], n=n, nc=num_coarse, nf=nf, noise_std=float(noise_std), white=bool(white), prec=prec)
     return (rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f, dex), saved
 
 
@@ -445,8 +482,10 @@ def render_rays_backward(packed_c, packed_f, saved, g_c, g_f, views_c, views_f, 
     n, nc, nf = saved["n"], saved["nc"], saved["nf"]
     fine = nf > 0 and packed_f is not None
 
+    prec = saved["prec"]
+
     def grads_buf(packed, n_points):
-        return torch.empty(train_sizes(packed, n_points)[2], dtype=torch.uint8, device=dev)
+        return torch.empty(train_sizes(packed, n_points, prec=prec)[2], dtype=torch.uint8, device=dev)
     grads_c = grads_buf(packed_c, n * nc) if nets & 1 else None
     grads_f = grads_buf(packed_f, n * (nc + nf)) if (fine and nets & 2) else None
 
@@ -459,7 +498,7 @@ def render_rays_backward(packed_c, packed_f, saved, g_c, g_f, views_c, views_f, 
     gs = [None if g is None else f32c(g) for g in tuple(g_c) + tuple(g_f)]
     check(lib().dn_render_rays_backward(
         ctypes.byref(packed_c.desc), ptr(packed_c.buffer_bwd),
-        ctypes.byref(packed_f.desc) if fine else None, ptr(packed_f.buffer_bwd) if fine else None, packed_c.precision,
+        ctypes.byref(packed_f.desc) if fine else None, ptr(packed_f.buffer_bwd) if fine else None, prec,
         ptr(saved["rays"]), saved["rays"].shape[1], n, nc, nf, saved["noise_std"], int(saved["white"]),
         ptr(saved["noise_c"]), ptr(saved["noise_f"]), ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]), ptr(gs[5]),
         ptr(saved["ws"]), ptr(saved["act_c"]), ptr(saved["masks_c"]), ptr(grads_c), ptr(saved["act_f"]), ptr(saved["masks_f"]),

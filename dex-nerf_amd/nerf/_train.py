@@ -65,11 +65,12 @@ class FusedNetFn(torch.autograd.Function):
         if pk.key_bwd != key or torch.cuda.is_current_stream_capturing():
             _ops.pack_backward(pk, [m.weight for m in mods])
             pk.key_bwd = key
+        prec = _ops.train_precision(pk)
         if samples_per_ray is None:
-            out, act, masks = _ops.run_network_train(pk, None, None, None, rays=pts, z_vals=viewdirs)
+            out, act, masks = _ops.run_network_train(pk, None, None, None, rays=pts, z_vals=viewdirs, prec=prec)
         else:
-            out, act, masks = _ops.run_network_train(pk, pts, viewdirs, samples_per_ray)
-        ctx.model, ctx.pk = model, pk
+            out, act, masks = _ops.run_network_train(pk, pts, viewdirs, samples_per_ray, prec=prec)
+        ctx.model, ctx.pk, ctx.prec = model, pk, prec
         ctx.n_points = out.shape[0]
         ctx.save_for_backward(act, masks)
         ctx.sink = getattr(model, "_grad_sink", None)
@@ -82,7 +83,7 @@ class FusedNetFn(torch.autograd.Function):
         model, pk, n = ctx.model, ctx.pk, ctx.n_points
         act, masks = ctx.saved_tensors
         g_out = g_out.contiguous().float()
-        grads = _ops.mlp_backward_data(pk, g_out, masks, n)
+        grads = _ops.mlp_backward_data(pk, g_out, masks, n, prec=ctx.prec)
         slots, gslots, kh = _slots(model, pk.precision)
         w, d, dev = model.hidden_size, model.num_layers, g_out.device
 
@@ -108,10 +109,10 @@ class FusedNetFn(torch.autograd.Function):
             if views is not None:
                 # the parameters' `.grad` are views of a FlatGradBucket: accumulate straight into them (nothing goes back
                 # through autograd's accumulation), then let the bucket start this network's all-reduce
-                _ops.mlp_weight_grad_all_into(pk, act, grads, n, views)
+                _ops.mlp_weight_grad_all_into(pk, act, grads, n, views, prec=ctx.prec)
                 ctx.sink.backward_done()
                 return (None,) * (6 + 2 * len(mods))
-            res = _ops.mlp_weight_grad_all(pk, act, grads, n, [tuple(m.weight.shape) for m in mods])
+            res = _ops.mlp_weight_grad_all(pk, act, grads, n, [tuple(m.weight.shape) for m in mods], prec=ctx.prec)
             flat = []
             for d_w, d_b in res:
                 flat.extend((d_w, d_b))

@@ -172,15 +172,14 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pos
            "what": "ray selection + fwd + bwd + fused Adam, 64+128 samples, perturb + noise 0.2, D8/W256 x2, fused HIP training kernels"}
     # roofline of the step: HBM-bound by construction - the saved activations and gradients are written
     # once by the forward / backward chains and read once by the weight-gradient kernel; MFMA rate beside it (3x forward FLOP)
-    prec = _hip.PREC_BF16 if nerf.get_precision() == "bf16" else _hip.PREC_F32
     nbytes = 0
     for m, s in ((models[0], NC), (models[1], NC + NF)):
-        a, mk, g = _ops.train_sizes(m.packed(), n_rays * s)
+        a, mk, g = _ops.train_sizes(m.packed(), n_rays * s, prec=_ops.train_precision(m.packed()))
         nbytes += 2 * (a + g) + 2 * mk + n_rays * s * (16 + 16 + 4) * 2   # + rf / g_rf / z through compositing
     flops = 3.0 * n_rays * POINTS_PER_RAY * FLOP_PER_POINT
     res["roofline"] = {"bound": "hbm", "achieved": nbytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / dt / 8e12,
                        "bytes_per_step": nbytes, "mfma_tflops": flops / dt / 1e12,
-                       "mfma_frac": flops / dt / 1e12 / PEAK_TFLOPS[nerf.get_precision()],
+                       "mfma_frac": flops / dt / 1e12 / PEAK_TFLOPS[nerf.get_precision().split("-")[0]],
                        "what": "algorithmic bytes per step per GPU = 2 x (saved activations + saved gradients) + 2 x ReLU masks "
                                "(dn_mlp_train_sizes, both nets) + the radiance-field tensors through compositing; whole step time"}
     if dist is not None:
@@ -383,6 +382,13 @@ def main():
         if not args.no_train and world == 1:
             result["train"] = train_rate(models, cfg, ro, rd, ex, ed)
         if not args.no_train and world == 1 and args.precision == "bf16":
+            # the same iteration with the tensors saved for the backward at 8 bits (same forward bits)
+            nerf.set_precision("bf16-s8")
+            try:
+                models8, cfg8, _, _, _, _ = build_scene(dev, rank)
+                result["train_s8_mode"] = train_rate(models8, cfg8, ro, rd, ex, ed)
+            finally:
+                nerf.set_precision(args.precision)
             # the same iteration in the exact-fp32 parity mode (BASELINE config 5 trains in fp32): informational
             nerf.set_precision("fp32")
             try:

@@ -10,6 +10,8 @@
 // the end of this file (bf16 MFMA, or exact-fp32 MFMA in the parity mode).
 // In practice bound by the HBM write stream of the stored gradients (3.6 KiB/point at D8/W256), not by the MFMAs.
 #include "mlp_internal.h"
+#include <atomic>
+#include <cmath>
 
 namespace dn {
 
@@ -29,7 +31,10 @@ struct BwdParams {
   float grad_scale;        // S8 kernels: the power of two the gradients are multiplied by before they are rounded to e5m2
 };
 
-static thread_local float g_s8_grad_scale = 65536.0f;   // dn_set_s8_grad_scale: gradient scale of the 8-bit saved tensors
+// dn_set_s8_grad_scale: gradient scale of the 8-bit saved tensors.  Process-wide, not per thread: PyTorch runs the backward of a
+// step on its autograd thread, and the backward-data kernel (which multiplies) and the weight-gradient kernel (which divides)
+// must see the value the caller set on its own thread.
+static std::atomic<float> g_s8_grad_scale{65536.0f};
 
 constexpr int kBwdWaveLds = 6 * kPieceBytes;  // per wave: 2 output-gradient slots + 4 mask-word slots (1 KiB each)
 
@@ -427,7 +432,7 @@ extern "C" int dn_mlp_backward_data(const dn_mlp_desc* desc, int precision, cons
     DN_REQUIRE(t.gslot_dirout % 2 == 0 && t.gslot_feat % 2 == 0 && t.gslot_trunk0 % 2 == 0 && t.gslot_layer1 % 2 == 0 && t.gslot_out % 2 == 0,
                "dn_mlp_backward_data (8-bit saved tensors): odd gradient slot");
     p.grad_pieces = (t.grad_pieces + 1) / 2;
-    p.grad_scale = g_s8_grad_scale;
+    p.grad_scale = g_s8_grad_scale.load();
     if (desc->hidden_size == 256) return launch_backward<256, 1, true>(p, as_stream(stream));
     if (desc->hidden_size == 128) return launch_backward<128, 1, true>(p, as_stream(stream));
   }
@@ -1144,7 +1149,7 @@ static int wg_fill(const dn_mlp_desc* desc, const TrainLayout& t, const void* ac
     p.dy_odd = p.g_slot & 1;
     p.g_slot /= 2; p.x_slot /= 2; p.pe_slot /= 2;
     p.act_pieces = (t.act_pieces + 1) / 2; p.grad_pieces = (t.grad_pieces + 1) / 2;
-    p.out_scale = 1.0f / g_s8_grad_scale;
+    p.out_scale = 1.0f / g_s8_grad_scale.load();
   }
   *out = p;
   return 0;
@@ -1305,8 +1310,10 @@ extern "C" int dn_mlp_weight_grad(const dn_mlp_desc* desc, int precision, const 
 }
 
 extern "C" int dn_set_s8_grad_scale(float scale) {
-  DN_REQUIRE(scale > 0.0f, "dn_set_s8_grad_scale: the scale must be positive");
-  g_s8_grad_scale = scale;
+  int e = 0;
+  DN_REQUIRE(scale > 0.0f && std::isfinite(scale) && std::frexp(scale, &e) == 0.5f,
+             "dn_set_s8_grad_scale: the scale must be a power of two (the scaling and its inverse are then exact)");
+  g_s8_grad_scale.store(scale);
   return 0;
 }
 
@@ -1324,6 +1331,6 @@ extern "C" int dn_mlp_convert_saved_s8(const dn_mlp_desc* desc, int which, const
                        t.act_pieces, 1.0f, static_cast<char*>(out_s8));
   else
     hipLaunchKernelGGL(convert_s8_kernel<1>, dim3(2048), dim3(256), 0, as_stream(stream), static_cast<const char*>(native_bf16), tiles,
-                       t.grad_pieces, g_s8_grad_scale, static_cast<char*>(out_s8));
+                       t.grad_pieces, g_s8_grad_scale.load(), static_cast<char*>(out_s8));
   return check_launch("dn_mlp_convert_saved_s8");
 }

@@ -112,7 +112,8 @@ def main(argv=None):
     ap.add_argument("--m-thres", type=int, default=100)
     ap.add_argument("--ir", action="store_true", help="IR head of train_nerf_ir.py / train_dexnerf_ir.py: MSE on the luminance "
                                                       "0.299 r + 0.587 g + 0.114 b of prediction and target (:260-263)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16-s8", "fp32"],
+                    help="bf16-s8: bf16 kernels, the tensors saved for the backward at 8 bits (nerf.set_precision)")
     ap.add_argument("--validate-every", type=int, default=500)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--save", default="", help="checkpoint path (reference dict format)")

@@ -530,7 +530,7 @@ def test_training_driver_ir_head_and_dex_config_shapes(dev):
         nerf.set_precision("fp32")
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16-s8"])
 def test_training_driver_learns_a_synthetic_scene(dev, precision):
     """End-to-end: the build-owned driver (reference loop: random view + random rays, MSE_c + MSE_f, Adam with the
     exponential LR, Dex threshold sweep) trains a 4x128 student on a teacher scene through the fused HIP training
@@ -1351,3 +1351,90 @@ def test_bench_multi_gpu_leg_rehearsal_two_ranks_one_gpu(dev):
     dp = line["train_dp"]
     assert dp["n_gpus"] == 2 and dp["rccl_ranks"] == 2 and dp["allreduce_bytes"] == 2 * 595844 * 4
     assert dp["rays_per_s"] > 0 and dp["allreduce_ms"] > 0 and dp["roofline"]["bound"] == "hbm"
+
+
+# ---- 8-bit saved tensors (DN_PREC_BF16_S8, nerf.set_precision("bf16-s8")) -----------------------------------------------------
+@pytest.mark.parametrize("depth,width,viewdirs", [(8, 256, True), (4, 128, True), (8, 256, False), (5, 128, False)])
+def test_s8_saved_tensors_are_the_bf16_ones_rounded(dev, depth, width, viewdirs):
+    """The training forward / backward-data kernels in DN_PREC_BF16_S8 compute exactly what the bf16 ones do (same radiance field,
+    same ReLU masks) and store what they save for the weight-gradient kernel at 8 bits: bit for bit the bf16 buffers put through
+    dn_mlp_convert_saved_s8 (e4m3 activations; e5m2 of gradient x 65536, saturated) at half the bytes.  Ragged point count."""
+    import nerf
+    from nerf import _hip, _ops
+    nerf.set_precision("bf16")
+    try:
+        torch.manual_seed(3)
+        m = nerf.models.FlexibleNeRFModel(num_layers=depth, hidden_size=width, skip_connect_every=3, num_encoding_fn_xyz=10,
+                                          num_encoding_fn_dir=4, use_viewdirs=viewdirs).to(dev)
+        pk = m.packed()
+        _ops.pack_backward(pk, [x.weight for x in m.linear_modules()])
+        n_rays, s = 37, 53
+        n = n_rays * s
+        pts = torch.rand(n, 3, device=dev) * 2 - 1
+        vd = torch.nn.functional.normalize(torch.randn(n_rays, 3, device=dev), dim=-1) if viewdirs else None
+        g_out = torch.randn(n, 4, device=dev) * 1e-4
+        out, act, masks = _ops.run_network_train(pk, pts, vd, s)
+        out8, act8, masks8 = _ops.run_network_train(pk, pts, vd, s, prec=_hip.PREC_BF16_S8)
+        assert torch.equal(out, out8) and torch.equal(masks, masks8)
+        assert act8.numel() * 2 <= act.numel() + act.numel() // 8 and act8.numel() < act.numel()
+        assert torch.equal(act8, _ops.convert_saved_s8(pk, 0, act, n))
+        grads = _ops.mlp_backward_data(pk, g_out, masks, n)
+        grads8 = _ops.mlp_backward_data(pk, g_out, masks8, n, prec=_hip.PREC_BF16_S8)
+        assert grads8.numel() < grads.numel()
+        assert torch.equal(grads8, _ops.convert_saved_s8(pk, 1, grads, n))
+        # and the fp8-MFMA weight-gradient kernel on them against the bf16 kernel on the bf16 buffers
+        shapes = [tuple(x.weight.shape) for x in m.linear_modules()]
+        ref = _ops.mlp_weight_grad_all(pk, act, grads, n, shapes)
+        got = _ops.mlp_weight_grad_all(pk, act8, grads8, n, shapes, prec=_hip.PREC_BF16_S8)
+        for (w16, b16), (w8, b8), mod in zip(ref, got, m.linear_modules()):
+            for a, b in ((w8, w16), (b8, b16)):
+                a, b = C(a).astype(np.float64).reshape(-1), C(b).astype(np.float64).reshape(-1)
+                cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+                assert cos > 0.99, (tuple(mod.weight.shape), cos)
+    finally:
+        nerf.set_precision("fp32")
+
+
+def test_s8_training_step_gradients(golden, dev):
+    """One whole training step (both D8/W256 nets, 64 + 128 samples, perturbed) in the three training modes: the 'bf16-s8' mode's
+    forward is the bf16 mode's bit for bit (same loss), and its parameter gradients are as close to the fp32 mode's as the bf16
+    mode's are (cosine per tensor; the gate: within 5e-3 of the bf16 mode's cosine against fp32 and >= 0.93 - layer1 of a bf16
+    step sits at 0.955 on these rays - and >= 0.998 against the bf16 mode's own gradient)."""
+    import nerf
+    from nerf import synthetic as syn
+    mkw = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+    sds = [{k: torch.from_numpy(v) for k, v in syn.synth_state_dict(seed, sigma_bias=-1.0, **mkw).items()} for seed in (41, 43)]
+    cfg = make_cfg(dict(num_coarse=64, num_fine=128, near=2.0, far=6.0, perturb=True, noise_std=0.0))
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    n = 1536
+    gen = torch.Generator().manual_seed(2)
+    ro = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3) + 0.01 * torch.randn(n, 3, generator=gen)
+    rd = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, -1.0]) + 0.3 * torch.randn(n, 3, generator=gen), dim=-1)
+    rays = torch.cat([ro, rd, torch.full((n, 1), 2.0), torch.full((n, 1), 6.0), rd], -1).to(dev)
+    target = torch.rand(n, 3, generator=gen).to(dev)
+    res = {}
+    try:
+        for prec in ("fp32", "bf16", "bf16-s8"):
+            nerf.set_precision(prec)
+            assert nerf.get_precision() == prec
+            models = []
+            for sd in sds:
+                m = nerf.models.FlexibleNeRFModel(**mkw); m.load_state_dict(sd); models.append(m.to(dev))
+            torch.manual_seed(9)
+            out = nerf.predict_and_render_radiance(rays, models[0], models[1], cfg, mode="train", encode_position_fn=ex,
+                                                   encode_direction_fn=ed, m_thres_cand=M_THRES)
+            loss = nerf.img2mse(out[0], target) + nerf.img2mse(out[3], target)
+            loss.backward()
+            res[prec] = (float(loss.detach()), [C(p.grad).astype(np.float64).reshape(-1) for m in models for p in m.parameters()])
+    finally:
+        nerf.set_precision("fp32")
+    assert res["bf16-s8"][0] == res["bf16"][0]
+    assert abs(res["bf16"][0] - res["fp32"][0]) < 5e-3 * abs(res["fp32"][0])
+
+    def cos(a, b):
+        return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+    for g8, g16, g32 in zip(res["bf16-s8"][1], res["bf16"][1], res["fp32"][1]):
+        assert cos(g8, g32) > 0.93 and cos(g8, g32) > cos(g16, g32) - 5e-3, (cos(g8, g32), cos(g16, g32))
+        assert cos(g8, g16) > 0.998, cos(g8, g16)
+    whole = [np.concatenate(res[p][1]) for p in ("fp32", "bf16", "bf16-s8")]
+    assert cos(whole[2], whole[0]) > 0.995

@@ -66,6 +66,18 @@ def test_argument_validation_needs_no_gpu(hiplib):
     assert hiplib.dn_render_rays_train(ctypes.byref(d), null, ctypes.byref(d), null, 1, null, 11, 0, 64, 128, 0, 0.0, 0, None, 0,
                                        null, null, null, null, null, null, null, null, null, null, null, null, null, null,
                                        null, null, null) == 0     # zero rays: nothing to do
+    # 8-bit saved tensors (DN_PREC_BF16_S8): the same tiles at one 1 KiB unit per PAIR of bf16 pieces; bf16 arithmetic only
+    d.hidden_size = 256
+    sizes = {}
+    for prec in (_hip.PREC_BF16, _hip.PREC_BF16_S8):
+        a, m, g = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        assert hiplib.dn_mlp_train_sizes(ctypes.byref(d), prec, 1000, ctypes.byref(a), ctypes.byref(m), ctypes.byref(g)) == 0
+        sizes[prec] = (a.value, m.value, g.value)
+    a16, m16, g16 = sizes[_hip.PREC_BF16]
+    a8, m8, g8 = sizes[_hip.PREC_BF16_S8]
+    assert m8 == m16 and a16 == 2 * a8 and g8 * 2 - g16 in (0, 32 * 1024)   # (1000 points = 32 tiles of 32; an odd piece count pads one unit per tile)
+    assert hiplib.dn_set_s8_grad_scale(3.0) == -1000 and b"power of two" in hiplib.dn_last_error()
+    assert hiplib.dn_set_s8_grad_scale(65536.0) == 0
     with pytest.raises(RuntimeError):
         _hip.check(-1000, "probe")
 

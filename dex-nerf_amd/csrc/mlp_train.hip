@@ -571,12 +571,6 @@ __device__ __forceinline__ long tr8_frag(const char* unit_lane /* unit base + od
   return __builtin_bit_cast(long, v);
 }
 
-// feature index (within a 32-feature tile) that transposed fragment row/column `i` (0..31) refers to
-__device__ __forceinline__ int tr_feature(int i) {
-  const int fs = i >> 4, li = i & 15;
-  return acc_row(fs * 8 + (li & 7), li >> 3);
-}
-
 // s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -602,7 +596,11 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
   // receives feature column li; group g covers feature sub-block fs = g&1 and k-half hh = g>>1 of the MFMA operand
   const int li = lane & 15, grp = lane >> 4;
   const int fs = grp & 1, hh = grp >> 1;
-  const int lane_off = S::S8 ? (((li & 1) * 32 + (li >> 1) + 8 * hh) * 16)
+  // (8-bit units: a group reads the 8 x 16-byte rows [8 bytes of piece 2u | 8 bytes of piece 2u+1] that the lanes (point, lane
+  // half fs) stored - 128 CONTIGUOUS bytes, every LDS bank once.  Reading the two lane halves of one piece side by side, as the
+  // bf16 form has to, puts a group's chunk pairs 512 bytes apart = on the same bank: PMC showed one conflict cycle per two
+  // LDS cycles.  The price is a permuted feature order inside the 32-wide tile: s8_feature below.)
+  const int lane_off = S::S8 ? ((fs * 32 + (li >> 1) + 8 * hh) * 16) + (li & 1) * 8
                              : ((((li & 3) >> 1) * 32 + (li >> 2) + 8 * hh) * 16) + ((li & 3) & 1) * 8;
 
   // ---- staging: each 1 KiB piece is one LDS-DMA (opaque asm: the counted waits below are ours; hipcc would drain
@@ -716,13 +714,13 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
   auto consume_s8 = [&](long long tile, int cb) {
     const char* base = smem + cb * BUF + lane_off;
     constexpr long kOnes = 0x3838383838383838L;   // 1.0 in e4m3, eight times
-    // A = dY^T (e5m2): unit `ntile` holds both pieces of the n-tile, fs picks the half; a custom dY is half dy_odd of its unit
-    const char* dy = base + (S::CUSTOM ? p.dy_odd * 8 : ntile * kPieceBytes + fs * 8);
+    // A = dY^T (e5m2): unit `ntile` holds both pieces of the n-tile (fragment row 16 fs + li = piece li >> 3, lane half fs, element li & 7)
+    const char* dy = base + (S::CUSTOM ? 0 : ntile * kPieceBytes);
     long a0 = tr8_frag(dy, 0);
     long a1 = tr8_frag(dy, 16);
-    if constexpr (S::CUSTOM) {
-      a0 = fs ? 0L : a0;
-      a1 = fs ? 0L : a1;
+    if constexpr (S::CUSTOM) {   // a custom dY is piece dy_odd of its unit: the columns of the other piece are not its rows
+      a0 = ((li >> 3) != p.dy_odd) ? 0L : a0;
+      a1 = ((li >> 3) != p.dy_odd) ? 0L : a1;
     }
     const long long valid = p.n_points - tile * 32;  // points of this tile that exist (the rest are padding copies)
     if (valid < 32) {
@@ -739,14 +737,14 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
       if constexpr (S::KGROUPS == 1) {
         if constexpr (j == S::KT - 1) { b0 = kOnes; b1 = kOnes; }
         else {
-          const char* pb = base + (S::N_DY + j) * kPieceBytes + fs * 8;
+          const char* pb = base + (S::N_DY + j) * kPieceBytes;
           b0 = tr8_frag(pb, 0);
           b1 = tr8_frag(pb, 16);
         }
       } else {
         const int kt = kgroup + j * S::KGROUPS;           // wave-uniform; kt >= KT: an unused accumulator
         const int ktr = kt < S::KT - 1 ? kt : S::KT - 2;  // a unit that exists
-        const char* pb = base + (S::N_DY + ktr) * kPieceBytes + fs * 8;
+        const char* pb = base + (S::N_DY + ktr) * kPieceBytes;
         b0 = tr8_frag(pb, 0);
         b1 = tr8_frag(pb, 16);
         const bool is_ones = kt >= S::KT - 1;
@@ -816,19 +814,26 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
     constexpr int j = decltype(j_c)::value;
     const int kt = kgroup + j * S::KGROUPS;
     if (kt < S::KT) {
+      // fragment row / column i (0..31) = (piece s of the tile's two, lane half h, element e): bf16 reads i = 16 s + 8 h + e,
+      // the 8-bit reads i = 16 h + 8 s + e (see lane_off)
+      auto piece_of = [](int i) { return S::S8 ? (i >> 3) & 1 : i >> 4; };
+      auto half_of = [](int i) { return S::S8 ? i >> 4 : (i >> 3) & 1; };
+      auto feature_of = [&](int i) { return acc_row(piece_of(i) * 8 + (i & 7), half_of(i)); };
       int col;
-      if (kt < S::XT) col = 32 * kt + tr_feature(jl);
+      if (kt < S::XT) col = 32 * kt + feature_of(jl);
       else if (kt < S::KT - 1) {
-        const int pe_piece = 2 * (kt - S::XT) + (jl >> 4);
-        const int pc = pe_slot_col(p.pe_L, (jl & 15) >> 3, pe_piece * 8 + (jl & 7));
+        const int pe_piece = 2 * (kt - S::XT) + piece_of(jl);
+        const int pc = pe_slot_col(p.pe_L, half_of(jl), pe_piece * 8 + (jl & 7));
         col = pc >= 0 ? p.col_pe0 + pc : -1;
       } else col = (jl == 0) ? -2 : -1;  // all-ones tile: column 0 carries the bias gradient
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int irow = acc_row(r, half);
-        int n = 32 * ntile + tr_feature(irow);
+        int n = 32 * ntile + feature_of(irow);
         if constexpr (S::CUSTOM) {
-          n = (irow < 16) ? ((irow & 15) >> 3) * 8 + (irow & 7) : p.custom_rows;  // custom piece: row = 8h + e
+          // custom piece: row = 8h + e (bf16: the tile's piece 0; 8-bit: piece dy_odd of the unit - the other one was zeroed)
+          const bool mine = S::S8 ? piece_of(irow) == p.dy_odd : irow < 16;
+          n = mine ? half_of(irow) * 8 + (irow & 7) : p.custom_rows;
           if (n >= p.custom_rows) continue;
         }
 #if DN_WG_EPI == 1

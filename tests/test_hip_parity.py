@@ -951,6 +951,7 @@ def test_fp32_weight_grad_kernel_against_unpacked_gemms(dev):
     import nerf
     from nerf import _ops, _train, synthetic as syn
     nerf.set_precision("fp32")
+    torch.manual_seed(17)
     for kw in (dict(num_layers=8, hidden_size=256, skip_connect_every=4), dict(num_layers=5, hidden_size=128, skip_connect_every=2),
                dict(num_layers=3, hidden_size=128, skip_connect_every=4, use_viewdirs=False)):
         kw = dict(dict(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True), **kw)
@@ -992,7 +993,10 @@ def test_fp32_weight_grad_kernel_against_unpacked_gemms(dev):
         for mod, dy, x in checks:
             d_w, d_b = res[mod]
             assert rel_err(C(d_w), C(dy.t() @ x)) < 2e-5, (kw, mod)
-            assert rel_err(C(d_b), C(dy.sum(0))) < 2e-5, (kw, mod)
+            # (a bias gradient is a sum of ~1000 signed terms, for fc_alpha a single number: the fp32 rounding of the partial sums is
+            # relative to the terms, not to a result that may cancel to a hundredth of them)
+            db_err = np.abs(C(d_b).astype(np.float64) - C(dy.sum(0))).max()
+            assert db_err < 2e-5 * max(np.abs(C(dy.sum(0))).max(), 1e-2 * float(dy.abs().sum(0).max())), (kw, mod, db_err)
 
 
 @pytest.mark.parametrize("prec16", ["bf16", "fp16"])

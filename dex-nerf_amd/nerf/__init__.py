@@ -3,8 +3,8 @@
 Same public names as the reference's nerf/__init__.py:1-8 star-exports, for the ray-marching hot path:
 ray generation, stratified + hierarchical sampling, positional encoding, the coarse/fine MLPs and
 alpha compositing with the Dex fixed-sigma depth readout all run in hand-written HIP kernels
-(libdexnerf_hip.so) whenever tensors live on the ROCm device.  The Blender / MessyTable loaders and the ray-cache format are
-host-side numpy + PIL (nerf/datasets.py); the LLFF loader is not part of this build.
+(libdexnerf_hip.so) whenever tensors live on the ROCm device.  The Blender / MessyTable / LLFF loaders and the ray-cache format are
+host-side numpy + PIL (nerf/datasets.py, nerf/llff.py).
 """
 from . import models, parallel, synthetic  # noqa: F401  (scripts use getattr(models, cfg.models.coarse.type))
 from ._ops import get_precision, set_precision  # noqa: F401

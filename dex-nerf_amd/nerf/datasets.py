@@ -172,9 +172,7 @@ def load_messytable_data(basedir, half_res=False, testskip=1, debug=False, imgna
             torch.from_numpy(intrinsics), _shrink_all(depths, size, resize_nearest))
 
 
-def load_llff_data(*args, **kwargs):
-    raise NotImplementedError("load_llff_data: the LLFF loader (reference nerf/load_llff.py, 354 lines of pose recentring and "
-                              "COLMAP conventions) is not part of this build; none of the Dex-NeRF configurations use it")
+from .llff import load_llff_data  # noqa: E402,F401  (LLFF captures: nerf/llff.py)
 
 
 # ---- cached rays (reference cache_dataset.py:62-135) ------------------------------------------------------------

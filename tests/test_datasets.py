@@ -168,10 +168,123 @@ def test_ray_cache_round_trip(tmp_path):
         assert (h, w, f) == (5, 7, 12.5) and torch.equal(ro2, ro) and torch.equal(rd2, rd) and torch.equal(t2, tgt)
 
 
-def test_llff_loader_is_explicitly_absent():
+# ---- LLFF captures (nerf/llff.py; reference nerf/load_llff.py - parity unpinned, see the module header) ----------------------
+def _llff_rows(c2w_nerf, h, w, f, near, far):
+    """poses_bounds.npy rows from NeRF-frame (right, up, back) camera-to-world blocks: LLFF stores (down, right, back)."""
+    rows = []
+    for m in c2w_nerf:
+        right, up, back, t = m[:, 0], m[:, 1], m[:, 2], m[:, 3]
+        block = np.stack([-up, right, back, t, np.array([h, w, f], dtype=np.float64)], axis=1)     # 3 x 5
+        rows.append(np.concatenate([block.reshape(-1), [near, far]]))
+    return np.stack(rows)
+
+
+def _look_at(position, target, up=(0.0, 0.0, 1.0)):
+    back = position - target
+    back = back / np.linalg.norm(back)
+    right = np.cross(up, back); right /= np.linalg.norm(right)
+    return np.stack([right, np.cross(back, right), back, position], axis=1)
+
+
+def _write_capture(root, c2w, h, w, f, near, far, factor_dir=None, rng=None):
+    rng = rng or np.random.default_rng(0)
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    np.save(os.path.join(root, "poses_bounds.npy"), _llff_rows(c2w, h, w, f, near, far))
+    full = []
+    for i in range(len(c2w)):
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        Image.fromarray(img).save(os.path.join(root, "images", f"{i:03d}.png"))
+        full.append(img)
+    if factor_dir:
+        os.makedirs(os.path.join(root, f"images_{factor_dir}"), exist_ok=True)
+        for i, img in enumerate(full):
+            Image.fromarray(img[::factor_dir, ::factor_dir]).save(os.path.join(root, f"images_{factor_dir}", f"{i:03d}.png"))
+    return full
+
+
+def test_llff_forward_facing_capture(tmp_path):
+    """A 3 x 3 grid of cameras on the plane z = 2 looking down -z: known average camera, bounds scaling, hold-out, spiral."""
     import nerf
-    with pytest.raises(NotImplementedError):
-        nerf.load_llff_data("/nonexistent")
+    from nerf import llff
+    grid = [np.array([x, y, 2.0]) for y in (-0.5, 0.0, 0.5) for x in (-0.6, 0.0, 0.6)]
+    c2w = [np.stack([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0], g], axis=1) for g in grid]      # right = +x, up = +y, back = +z
+    full = _write_capture(str(tmp_path), c2w, 16, 24, 40.0, near=1.5, far=9.0, factor_dir=2)
+    images, poses, bds, render_poses, i_test = nerf.load_llff_data(str(tmp_path), factor=2)
+    assert images.shape == (9, 8, 12, 3) and images.dtype == np.float32
+    np.testing.assert_allclose(images[4], full[4][::2, ::2].astype(np.float32) / 255.0, atol=1e-7)   # an existing images_2/ is read as it is
+    assert poses.shape == (9, 3, 5) and poses.dtype == np.float32 and bds.shape == (9, 2)
+    np.testing.assert_allclose(poses[:, :, 4], np.tile([8.0, 12.0, 20.0], (9, 1)))                   # h, w of the loaded images, f / factor
+    scale = 1.0 / (1.5 * 0.75)
+    np.testing.assert_allclose(bds, np.tile([1.5 * scale, 9.0 * scale], (9, 1)), rtol=1e-6)          # nearest bound at 1 / bd_factor
+    # recentred: the grid is symmetric, so the average camera was (identity rotation, centre (0, 0, 2 scale)) -> poses = grid offsets
+    np.testing.assert_allclose(poses[:, :, :3], np.tile(np.eye(3), (9, 1, 1)), atol=1e-6)
+    np.testing.assert_allclose(poses[:, :, 3], np.array([[g[0] * scale, g[1] * scale, 0.0] for g in grid]), atol=1e-6)
+    np.testing.assert_allclose(llff.average_pose(poses)[:, :4], np.eye(4)[:3], atol=1e-6)
+    assert i_test == 4                                                                               # the centre view
+    # spiral: 120 views, two turns, radii = 90th percentile of |offsets|, every pose looks at the focus point on the average axis
+    assert render_poses.shape == (120, 3, 5) and render_poses.dtype == np.float32
+    near, far = bds.min() * 0.9, bds.max() * 5.0
+    focus = np.array([0.0, 0.0, -1.0 / (0.25 / near + 0.75 / far)])
+    rads = np.percentile(np.abs(poses[:, :, 3]), 90, axis=0)
+    for k in (0, 17, 60, 119):
+        t = 4.0 * np.pi * k / 120
+        np.testing.assert_allclose(render_poses[k, :, 3], [np.cos(t) * rads[0], -np.sin(t) * rads[1], 0.0], atol=1e-5)
+        np.testing.assert_allclose(render_poses[k, :, 2], (render_poses[k, :, 3] - focus) / np.linalg.norm(render_poses[k, :, 3] - focus), atol=1e-5)
+        np.testing.assert_allclose(render_poses[k, :, :3].T @ render_poses[k, :, :3], np.eye(3), atol=1e-5)
+        np.testing.assert_allclose(render_poses[k, :, 4], [8.0, 12.0, 20.0])
+    # path_zflat: one turn of 60 views in the plane shifted along the viewing axis
+    flat = nerf.load_llff_data(str(tmp_path), factor=2, path_zflat=True)[3]
+    assert flat.shape == (60, 3, 5)
+    np.testing.assert_allclose(flat[:, 2, 3], near * 0.1 * -1.0 * 1.0, atol=1e-5)                    # zloc = -0.1 near along the back axis (0, 0, 1)
+    # bd_factor=None leaves the capture's scale; recenter=False its frame
+    raw = nerf.load_llff_data(str(tmp_path), factor=2, bd_factor=None, recenter=False)
+    np.testing.assert_allclose(raw[1][:, :, 3], np.array(grid), atol=1e-6)
+    np.testing.assert_allclose(raw[2], np.tile([1.5, 9.0], (9, 1)))
+
+
+def test_llff_missing_factor_directory_is_shrunk_in_memory(tmp_path):
+    """No images_4/ on disk: the reference shells out to mogrify; here images/ is area-averaged in memory (module header)."""
+    import nerf
+    from nerf import datasets as D
+    c2w = [np.stack([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0], np.array([x, 0.0, 0.0])], axis=1) for x in (-1.0, 0.0, 1.0)]
+    full = _write_capture(str(tmp_path), c2w, 16, 32, 64.0, near=2.0, far=6.0)
+    images, poses, _, _, _ = nerf.load_llff_data(str(tmp_path), factor=4)
+    assert images.shape == (3, 4, 8, 3)
+    np.testing.assert_allclose(poses[:, :, 4], np.tile([4.0, 8.0, 16.0], (3, 1)))
+    np.testing.assert_allclose(images[1], D.resize_area(full[1].astype(np.float32) / 255.0, 4, 8), atol=1e-6)
+    with pytest.raises(ValueError, match="images for"):                                              # pose / image count mismatch is an error, not a print
+        os.remove(os.path.join(str(tmp_path), "images", "002.png"))
+        nerf.load_llff_data(str(tmp_path), factor=1)
+
+
+def test_llff_spherified_capture(tmp_path):
+    """Inward-facing ring of cameras around (1, 2, 3): spherify moves the focus to the origin, puts the cameras at RMS distance
+    1 with the mean offset along +z, and returns a circular path at their height, every pose facing outwards along its position."""
+    import nerf
+    centre = np.array([1.0, 2.0, 3.0])
+    cams = []
+    for k in range(12):
+        a = 2 * np.pi * k / 12
+        cams.append(_look_at(centre + np.array([2.5 * np.cos(a), 2.5 * np.sin(a), 1.0 + 0.2 * (k % 2)]), centre))
+    _write_capture(str(tmp_path), cams, 8, 8, 10.0, near=1.0, far=5.0)
+    images, poses, bds, render_poses, i_test = nerf.load_llff_data(str(tmp_path), factor=1, spherify=True)
+    pos = poses[:, :, 3].astype(np.float64)
+    np.testing.assert_allclose(np.sqrt((pos ** 2).sum(-1).mean()), 1.0, rtol=1e-5)                   # RMS radius 1
+    mean_offset = pos.mean(0)
+    assert mean_offset[2] > 0 and np.abs(mean_offset[:2]).max() < 1e-5                               # mean camera offset along +z
+    for m in poses:                                                                                  # every optical axis still passes through the (moved) focus = origin
+        axis, o = m[:, 2].astype(np.float64), m[:, 3].astype(np.float64)
+        assert np.linalg.norm(np.cross(axis, o)) < 1e-5
+    assert render_poses.shape == (120, 3, 5)
+    rp = render_poses.astype(np.float64)
+    np.testing.assert_allclose(np.linalg.norm(rp[:, :, 3], axis=-1), 1.0, rtol=1e-5)
+    np.testing.assert_allclose(rp[:, 2, 3], mean_offset[2], rtol=1e-5)
+    np.testing.assert_allclose(rp[:, :, 2], rp[:, :, 3], atol=1e-5)                                  # back axis = unit position
+    # bounds share the scale of the translations: near was 1.0 -> 1 / 0.75 after bd_factor, then x 1 / radius
+    unscaled = nerf.load_llff_data(str(tmp_path), factor=1, spherify=False)
+    ratio = float(bds[0, 0] / unscaled[2][0, 0])
+    np.testing.assert_allclose(bds, unscaled[2] * ratio, rtol=1e-6)
+    assert 0 <= i_test < 12
 
 
 def test_cache_dataset_cli(tmp_path):

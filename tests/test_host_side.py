@@ -159,8 +159,6 @@ def test_hot_path_refuses_host_tensors():
     with pytest.raises(RuntimeError, match="ROCm device"):
         nerf.run_network(m, torch.zeros(2, 4, 3), torch.zeros(2, 11), 16, nerf.get_embedding_function(6),
                          nerf.get_embedding_function(4))
-    with pytest.raises(NotImplementedError):
-        nerf.load_llff_data("x")
 
 
 def test_product_never_imports_the_oracle():

@@ -737,9 +737,13 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
       if constexpr (S::KGROUPS == 1) {
         if constexpr (j == S::KT - 1) { b0 = kOnes; b1 = kOnes; }
         else {
+#ifndef DN_WG_NOREAD
           const char* pb = base + (S::N_DY + j) * kPieceBytes;
           b0 = tr8_frag(pb, 0);
           b1 = tr8_frag(pb, 16);
+#else
+          b0 = kOnes; b1 = kOnes;
+#endif
         }
       } else {
         const int kt = kgroup + j * S::KGROUPS;           // wave-uniform; kt >= KT: an unused accumulator

@@ -1442,3 +1442,54 @@ def test_s8_training_step_gradients(golden, dev):
         assert cos(g8, g16) > 0.998, cos(g8, g16)
     whole = [np.concatenate(res[p][1]) for p in ("fp32", "bf16", "bf16-s8")]
     assert cos(whole[2], whole[0]) > 0.99 and cos(whole[2], whole[0]) > cos(whole[1], whole[0]) - 1e-3, (cos(whole[2], whole[0]), cos(whole[1], whole[0]))
+
+
+def test_llff_capture_renders_through_the_ndc_branch(dev, tmp_path):
+    """SURVEY 8f N2 + S2b end to end: a forward-facing capture on disk in the LLFF layout -> nerf.load_llff_data -> 4-argument
+    get_ray_bundle (camera-to-world convention) -> run_one_iter_of_nerf with dataset.no_ndc = False (near 0, far 1: the LLFF
+    configs of train_nerf_rgb.py) against the same chunk rendered from rows warped with the reference's elementwise formula
+    (nerf_helpers.py:172-199 in torch ops; view directions from the UNwarped rays, train_utils.py:220-238)."""
+    import nerf
+    from PIL import Image
+    from nerf import synthetic as syn
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "images"))
+    rng = np.random.default_rng(1)
+    h, w, f = 20, 28, 30.0
+    rows = []
+    for k, (x, y) in enumerate([(x, y) for y in (-0.3, 0.0, 0.3) for x in (-0.4, 0.0, 0.4)]):
+        # LLFF block columns: (down, right, back, position, hwf) for a camera at (x, y, 0) looking down -z
+        block = np.stack([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0], [x, y, 0.0], [h, w, f]], axis=1)
+        rows.append(np.concatenate([block.reshape(-1), [2.0, 8.0]]))
+        Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(os.path.join(root, "images", f"{k:02d}.png"))
+    np.save(os.path.join(root, "poses_bounds.npy"), np.stack(rows))
+    images, poses, bds, render_poses, i_test = nerf.load_llff_data(root, factor=1)
+    assert images.shape == (9, h, w, 3) and i_test == 4 and render_poses.shape == (120, 3, 5)
+    hh, ww, focal = (int(poses[0, 0, 4]), int(poses[0, 1, 4]), float(poses[0, 2, 4]))
+    assert (hh, ww, focal) == (h, w, f)
+    pose = torch.from_numpy(np.vstack([render_poses[7, :3, :4], [[0, 0, 0, 1]]]).astype(np.float32)).to(dev)
+    ro, rd = nerf.get_ray_bundle(hh, ww, focal, pose)
+    mkw = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+    models = make_models(mkw, syn.synth_state_dict(5, sigma_bias=1.0, **mkw), syn.synth_state_dict(6, sigma_bias=1.0, **mkw), dev)
+    cfg = make_cfg(dict(num_coarse=32, num_fine=48, near=0.0, far=1.0))
+    cfg.dataset.no_ndc = False
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    with torch.no_grad():
+        out = nerf.run_one_iter_of_nerf(hh, ww, focal, models[0], models[1], ro, rd, cfg, mode="validation", encode_position_fn=ex,
+                                        encode_direction_fn=ed, m_thres_cand=M_THRES)
+        o, d = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        t = -(1.0 + o[:, 2]) / d[:, 2]
+        o = o + t[:, None] * d
+        sx, sy = -1.0 / (ww / (2.0 * focal)), -1.0 / (hh / (2.0 * focal))
+        wo = torch.stack([sx * o[:, 0] / o[:, 2], sy * o[:, 1] / o[:, 2], 1.0 + 2.0 / o[:, 2]], -1)
+        wd = torch.stack([sx * (d[:, 0] / d[:, 2] - o[:, 0] / o[:, 2]), sy * (d[:, 1] / d[:, 2] - o[:, 1] / o[:, 2]), -2.0 / o[:, 2]], -1)
+        vd = torch.nn.functional.normalize(rd.reshape(-1, 3), dim=-1)
+        rows = torch.cat([wo, wd, torch.zeros_like(wo[:, :1]), torch.ones_like(wo[:, :1]), vd], -1)
+        ref = nerf.predict_and_render_radiance(rows, models[0], models[1], cfg, mode="validation", encode_position_fn=ex,
+                                               encode_direction_fn=ed, m_thres_cand=M_THRES)
+    assert out[3].shape == (hh, ww, 3) and out[4].shape == (hh, ww)
+    for a, b in zip(out, ref):
+        assert rel_err(C(a).reshape(-1), C(b).reshape(-1)) < TOL
+    depth = C(out[4])
+    assert depth.min() >= 0.0 and depth.max() <= 1.0 + 1e-6          # NDC depths live in [0, 1]
+    assert 0.0 <= float(C(out[5]).min()) and float(C(out[5]).max()) <= 1.0 + 1e-5

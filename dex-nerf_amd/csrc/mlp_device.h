@@ -14,7 +14,7 @@
     (defined(DN_EXP_NODMA) || defined(DN_EXP_NOREAD) || defined(DN_EXP_SHALLOW) || defined(DN_EXP_LOOSEWAIT) ||    \
      defined(DN_EXP_NOBARRIER) || defined(DN_EXP_REGSTAGE) || defined(DN_EXP_ROTATE) || defined(DN_EXP_SETPRIO) || \
      defined(DN_EXP_NOPIN) || defined(DN_EXP_NOSAVE) || defined(DN_EXP_NOSETTLE) || defined(DN_STAMP) || defined(DN_STORE_POLICY_ID) || \
-     defined(DN_WG_NOREAD) || defined(DN_WG_NOSTAGE) || defined(DN_WG_EPI) || defined(DN_WG_LOAD_POLICY_ID))
+     defined(DN_WG_NOREAD) || defined(DN_WG_NOSTAGE) || defined(DN_WG_STAMP) || defined(DN_WG_EPI) || defined(DN_WG_LOAD_POLICY_ID))
 #error "DN_EXP_* / DN_WG_* / DN_STORE_POLICY_ID are ablation hooks: build them with scripts/build_exp.sh (-DDN_ABLATION_BUILD), never into libdexnerf_hip.so"
 #endif
 

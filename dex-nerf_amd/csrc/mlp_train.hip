@@ -11,6 +11,7 @@
 // In practice bound by the HBM write stream of the stored gradients (3.6 KiB/point at D8/W256), not by the MFMAs.
 #include "mlp_internal.h"
 #include <atomic>
+#include <vector>
 #include <cmath>
 
 namespace dn {
@@ -509,6 +510,9 @@ struct WgParams {
   // multiplied by before they were rounded to e5m2)
   int dy_odd;
   float out_scale;
+#ifdef DN_WG_STAMP
+  unsigned long long* stamp;      // diagnostic build: [workgroup][wave][8] accumulated s_memtime ticks
+#endif
 };
 
 constexpr int kWgLdsBytes = 144 * 1024;
@@ -770,21 +774,49 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
     long long tile = wg;
 #pragma unroll 1
     for (int st = 0; st + 1 < S::STAGES; ++st) stage(tile + static_cast<long long>(st) * n_wg, st);
+#ifdef DN_WG_STAMP
+    unsigned long long st_wait = 0, st_bar = 0, st_stage = 0, st_cons = 0, st_n = 0;
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll 1
     for (; tile < tiles; tile += n_wg) {
+#ifdef DN_WG_STAMP
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
       // this wave's DMAs of tile `tile` are done, and so are its LDS reads of the previous tile ...
       wait_tiles();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef DN_WG_STAMP
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
       // ... after the barrier everyone's are: the tile is resident and the previous tile's buffer is free
       __builtin_amdgcn_s_barrier();
+#ifdef DN_WG_STAMP
+      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
       {
         int nb = buf + S::STAGES - 1;
         if (nb >= S::STAGES) nb -= S::STAGES;
         stage(tile + static_cast<long long>(S::STAGES - 1) * n_wg, nb);
       }
+#ifdef DN_WG_STAMP
+      const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#endif
       consume(tile, buf);
+#ifdef DN_WG_STAMP
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+      st_wait += t1 - t0; st_bar += t2 - t1; st_stage += t3 - t2; st_cons += t4 - t3; st_n += 1;
+#endif
       buf = (buf + 1 == S::STAGES) ? 0 : buf + 1;
     }
+#ifdef DN_WG_STAMP
+    if (lane == 0 && p.stamp != nullptr) {
+      unsigned long long* o = p.stamp + (static_cast<long long>(blockIdx.x) * 8 + wave) * 8;
+      o[0] = st_wait; o[1] = st_bar; o[2] = st_stage; o[3] = st_cons; o[4] = st_n; o[5] = __builtin_amdgcn_s_memtime() - st_begin;
+      o[6] = static_cast<unsigned long long>(p.shape); o[7] = static_cast<unsigned long long>(S::J);
+    }
+#endif
   } else {
     // TPI tiles per barrier (small shapes: a tile is a few MFMAs per wave, the barrier + wait + LDS latency dominate)
     auto tile_of = [&](long long k) { return wg + k * n_wg; };
@@ -1286,6 +1318,13 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
     b.wg_begin[i + 1] = b.wg_begin[i] + share[i];
   }
   if ((rc = f32 ? wg_attr(weight_grad_batch_kernel_f32) : (s8 ? wg_attr(weight_grad_batch_kernel_s8) : wg_attr(weight_grad_batch_kernel)))) return rc;
+#ifdef DN_WG_STAMP   // diagnostic build: synchronous, allocates, prints - never part of the shipped library
+  static unsigned long long* stamp_buf = nullptr;
+  const size_t stamp_words = static_cast<size_t>(b.wg_begin[n_units]) * 8 * 8;
+  if (!stamp_buf) (void)hipMalloc(&stamp_buf, 1024 * 8 * 8 * sizeof(unsigned long long));
+  (void)hipMemsetAsync(stamp_buf, 0, stamp_words * sizeof(unsigned long long), as_stream(stream));
+  for (int i = 0; i < n_units; ++i) b.u[i].stamp = stamp_buf;
+#endif
   if (s8)
     hipLaunchKernelGGL(weight_grad_batch_kernel_s8, dim3(static_cast<unsigned>(b.wg_begin[n_units])), dim3(512), kWgLdsBytes,
                        as_stream(stream), b);
@@ -1295,6 +1334,26 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
   else
     hipLaunchKernelGGL(weight_grad_batch_kernel, dim3(static_cast<unsigned>(b.wg_begin[n_units])), dim3(512), kWgLdsBytes,
                        as_stream(stream), b);
+#ifdef DN_WG_STAMP
+  {
+    (void)hipStreamSynchronize(as_stream(stream));
+    std::vector<unsigned long long> h(stamp_words);
+    (void)hipMemcpy(h.data(), stamp_buf, stamp_words * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    for (int i = 0; i < n_units; ++i) {
+      double a[6] = {}; int waves = 0; double shape = -1, jj = 0;
+      for (int wgi = b.wg_begin[i]; wgi < b.wg_begin[i + 1]; ++wgi)
+        for (int w = 0; w < 8; ++w) {
+          const unsigned long long* o = &h[(static_cast<size_t>(wgi) * 8 + w) * 8];
+          if (o[4] == 0) continue;
+          for (int k = 0; k < 6; ++k) a[k] += static_cast<double>(o[k]);
+          shape = static_cast<double>(o[6]); jj = static_cast<double>(o[7]); ++waves;
+        }
+      if (waves)
+        fprintf(stderr, "[wg-stamp] unit %2d shape %2.0f J %2.0f, %3d workgroups: per tile: wait %.0f, barrier %.0f, stage %.0f, consume %.0f ticks; %.0f tiles per wave, loop %.0f ticks per wave\n",
+                i, shape, jj, b.wg_begin[i + 1] - b.wg_begin[i], a[0] / a[4], a[1] / a[4], a[2] / a[4], a[3] / a[4], a[4] / waves, a[5] / waves);
+    }
+  }
+#endif
   return check_launch("dn_mlp_weight_grad_all");
 }
 

@@ -544,8 +544,20 @@ struct WgShape {
   static constexpr int N_X = UPT * XT, N_PE = UPT * PET;
   static constexpr int PIECES = N_DY + N_X + N_PE;         // 1 KiB pieces staged per 32-point tile
   static constexpr int PER_WAVE = (PIECES + 7) / 8;        // DMAs per tile of the busiest wave
-  static constexpr int TPI = wg_tiles_per_iter(S8 ? 2 * PIECES : PIECES);   // tiles per barrier: by the MFMA count of a tile, not by its bytes
+  // 8-bit kernel: PAIRS of tiles contracted by the K = 64 fp8 MFMA (twice the K = 16 rate) wherever 24 operand registers fit
+  // beside the accumulators (J <= 9: all but the skip layer of a W = 256 net, which keeps the K = 16 form)
+  static constexpr bool K64 = S8 && J <= 9;
+  // tiles per barrier: by the MFMA count of a tile, not by its bytes
+  static constexpr int TPI0 = wg_tiles_per_iter(S8 ? 2 * PIECES : PIECES);
+  static constexpr int TPI = (K64 && TPI0 < 2) ? 2 : TPI0;
   static constexpr int STAGES = wg_stages_for(PIECES, TPI); // tile buffers in LDS; STAGES - TPI tiles in flight
+  // Cycles one 32-point tile costs a workgroup of this shape in the 8-bit kernel, fitted to -DDN_WG_STAMP runs (profiles/r02_train_s8.md;
+  // measured / model for the W = 256 shapes: (8,0,2) 678 / 746, (8,8,0) 1131 / 1134, (4,8,1) 940 / 1000, (1,8,0) 868 / 904, (8,8,2)
+  // 2123 / 2138): wait + barrier, ~100 issue cycles per LDS-DMA of the busiest wave, and the MFMAs of the two waves of a SIMD - K = 64:
+  // 64 cycles per accumulator tile and PAIR of tiles, but never less than the LDS round trips of a tile (~260); K = 16: 128 per tile.
+  // The 8-bit launch divides its workgroups among the layers by this, not by bytes: it is not HBM-bound.
+  static constexpr int COST = K64 ? 250 + 12 * J + 100 * PER_WAVE + (64 * J > 260 ? 64 * J : 260) + (KGROUPS > 1 ? 170 : 0) - (TPI >= 4 ? 100 : 0)
+                                  : 430 / TPI + 100 * PER_WAVE + 128 * J;
   static_assert(STAGES >= 2 * TPI && STAGES * PIECES * kPieceBytes <= 160 * 1024, "LDS budget");
   static_assert(XT + PET >= 1 && NTN * KGROUPS == 8, "shape");
 };
@@ -604,7 +616,8 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
   // half fs) stored - 128 CONTIGUOUS bytes, every LDS bank once.  Reading the two lane halves of one piece side by side, as the
   // bf16 form has to, puts a group's chunk pairs 512 bytes apart = on the same bank: PMC showed one conflict cycle per two
   // LDS cycles.  The price is a permuted feature order inside the 32-wide tile: s8_feature below.)
-  const int lane_off = S::S8 ? ((fs * 32 + (li >> 1) + 8 * hh) * 16) + (li & 1) * 8
+  // (the 8-bit kernel's MFMA contracts 64 points = a PAIR of tiles: hh selects the tile, the four reads of a lane its 32 points)
+  const int lane_off = S::S8 ? ((fs * 32 + (li >> 1)) * 16) + (li & 1) * 8
                              : ((((li & 3) >> 1) * 32 + (li >> 2) + 8 * hh) * 16) + ((li & 3) & 1) * 8;
 
   // ---- staging: each 1 KiB piece is one LDS-DMA (opaque asm: the counted waits below are ours; hipcc would drain
@@ -715,8 +728,80 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
     });
   };
+  // 8-bit buffers: tiles `tile0` (buffer cb0) and `tile1` (buffer cb1; tile1 >= tiles: absent) as ONE K = 64 contraction with
+  // v_mfma_f32_32x32x64_f8f6f4 (A = e5m2, B = e4m3, no scaling: twice the rate of the K = 16 fp8 / bf16 MFMAs).  Lane (row or
+  // column 16 fs + li, K block hh) holds 32 consecutive K slots = the 32 points of tile hh, four 8-point reads; A and B use the
+  // same slot order, which is all a contraction needs.
+  auto consume_pair_s8 = [&](long long tile0, int cb0, long long tile1, int cb1) {
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    const char* base = smem + (hh ? cb1 : cb0) * BUF + lane_off;
+    constexpr int kOnes = 0x38383838;   // 1.0 in e4m3, four times
+    auto read32 = [](const char* unit_lane) {   // this lane's 32 K slots of one operand: four 8-point transposing reads
+      i32x8 o;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(unit_lane + f * 128));
+        o[2 * f] = v[0]; o[2 * f + 1] = v[1];
+      }
+      return o;
+    };
+    // A = dY^T: unit `ntile` holds both pieces of the n-tile (fragment row 16 fs + li = piece li >> 3, lane half fs, element li & 7)
+    i32x8 av = read32(base + (S::CUSTOM ? 0 : ntile * kPieceBytes));
+    const long long mine = hh ? tile1 : tile0;
+    // points of this lane's tile that exist (the rest: padding copies, or a re-load standing in for an absent tile); a custom dY
+    // is piece dy_odd of its unit: the columns of the other piece are not its rows
+    int valid = mine < tiles ? static_cast<int>(p.n_points - mine * 32 < 32 ? p.n_points - mine * 32 : 32) : 0;
+    if constexpr (S::CUSTOM) valid = ((li >> 3) != p.dy_odd) ? 0 : valid;
+    if (valid < 32) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const int n = valid - 4 * d;   // K slots 4d .. 4d+3 (one per byte)
+        av[d] &= n >= 4 ? -1 : (n <= 0 ? 0 : static_cast<int>((1u << (8 * n)) - 1u));
+      }
+    }
+    auto load_b = [&](auto j_c) {
+      constexpr int j = decltype(j_c)::value;
+      i32x8 bv;
+      if constexpr (S::KGROUPS == 1) {
+        if constexpr (j == S::KT - 1) {
+#pragma unroll
+          for (int d = 0; d < 8; ++d) bv[d] = kOnes;
+        } else {
+#ifndef DN_WG_NOREAD
+          bv = read32(base + (S::N_DY + j) * kPieceBytes);
+#else
+#pragma unroll
+          for (int d = 0; d < 8; ++d) bv[d] = kOnes;
+#endif
+        }
+      } else {
+        const int kt = kgroup + j * S::KGROUPS;           // wave-uniform; kt >= KT: an unused accumulator
+        const int ktr = kt < S::KT - 1 ? kt : S::KT - 2;  // a unit that exists
+        bv = read32(base + (S::N_DY + ktr) * kPieceBytes);
+        const bool is_ones = kt >= S::KT - 1;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) bv[d] = is_ones ? kOnes : bv[d];
+      }
+      return bv;
+    };
+    // two k-tiles' operands ahead of the MFMA that uses them (the LDS round trip of four transposing reads is longer than one
+    // 16-pass MFMA), and no further: left alone the scheduler hoists all J x 8 operand registers above the first MFMA
+    i32x8 bq0 = load_b(std::integral_constant<int, 0>{});
+    i32x8 bq1 = bq0;
+    if constexpr (S::J > 1) bq1 = load_b(std::integral_constant<int, (S::J > 1 ? 1 : 0)>{});
+    static_for<S::J>([&](auto j_c) {
+      constexpr int j = decltype(j_c)::value;
+      i32x8 bnew = bq1;
+      if constexpr (j + 2 < S::J) bnew = load_b(std::integral_constant<int, (j + 2 < S::J ? j + 2 : 0)>{});
+      acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bq0, acc[j], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      bq0 = bq1;
+      bq1 = bnew;
+    });
+  };
+  // 8-bit buffers, one tile, K = 16 MFMAs: the shapes whose accumulators leave no room for the K = 64 operands (S::K64 false)
   auto consume_s8 = [&](long long tile, int cb) {
-    const char* base = smem + cb * BUF + lane_off;
+    const char* base = smem + cb * BUF + lane_off + hh * 128;   // (K = 16: lane group hh reads points 8 hh .. 8 hh + 7 of each 16)
     constexpr long kOnes = 0x3838383838383838L;   // 1.0 in e4m3, eight times
     // A = dY^T (e5m2): unit `ntile` holds both pieces of the n-tile (fragment row 16 fs + li = piece li >> 3, lane half fs, element li & 7)
     const char* dy = base + (S::CUSTOM ? 0 : ntile * kPieceBytes);
@@ -817,6 +902,54 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
       o[6] = static_cast<unsigned long long>(p.shape); o[7] = static_cast<unsigned long long>(S::J);
     }
 #endif
+  } else if constexpr (S::K64 && S::TPI == 2) {
+    // one PAIR of tiles per barrier, K = 64 (the big 8-bit shapes: the same minimal loop as above, two tiles at a time)
+    long long tile = wg;
+#pragma unroll 1
+    for (int st = 0; st + 2 < S::STAGES; ++st) stage(tile + static_cast<long long>(st) * n_wg, st);
+#ifdef DN_WG_STAMP
+    unsigned long long st_wait = 0, st_bar = 0, st_stage = 0, st_cons = 0, st_n = 0;
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll 1
+    for (; tile < tiles; tile += 2LL * n_wg) {
+#ifdef DN_WG_STAMP
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+      wait_tiles();   // this pair landed; STAGES - 4 younger tiles may be in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef DN_WG_STAMP
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+      __builtin_amdgcn_s_barrier();
+#ifdef DN_WG_STAMP
+      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
+      int nb = buf + S::STAGES - 2;
+      if (nb >= S::STAGES) nb -= S::STAGES;
+      stage(tile + static_cast<long long>(S::STAGES - 2) * n_wg, nb);
+      nb = (nb + 1 == S::STAGES) ? 0 : nb + 1;
+      stage(tile + static_cast<long long>(S::STAGES - 1) * n_wg, nb);
+      const int cb1 = (buf + 1 == S::STAGES) ? 0 : buf + 1;
+#ifdef DN_WG_STAMP
+      const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#endif
+      consume_pair_s8(tile, buf, tile + n_wg, cb1);
+#ifdef DN_WG_STAMP
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+      st_wait += t1 - t0; st_bar += t2 - t1; st_stage += t3 - t2; st_cons += t4 - t3; st_n += 2;   // (per TILE: two per iteration)
+#endif
+      buf += 2;
+      if (buf >= S::STAGES) buf -= S::STAGES;
+    }
+#ifdef DN_WG_STAMP
+    if (lane == 0 && p.stamp != nullptr) {
+      unsigned long long* o = p.stamp + (static_cast<long long>(blockIdx.x) * 8 + wave) * 8;
+      o[0] = st_wait; o[1] = st_bar; o[2] = st_stage; o[3] = st_cons; o[4] = st_n; o[5] = __builtin_amdgcn_s_memtime() - st_begin;
+      o[6] = static_cast<unsigned long long>(p.shape); o[7] = static_cast<unsigned long long>(S::J);
+    }
+#endif
   } else {
     // TPI tiles per barrier (small shapes: a tile is a few MFMAs per wave, the barrier + wait + LDS latency dominate)
     auto tile_of = [&](long long k) { return wg + k * n_wg; };
@@ -833,12 +966,23 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
         if (nb >= S::STAGES) nb -= S::STAGES;
         stage(tile_of(k0 + S::STAGES - S::TPI + t), nb);
       }
-      static_for<S::TPI>([&](auto t_c) {
-        constexpr int tsub = decltype(t_c)::value;
-        int cb = buf + tsub;
-        if (cb >= S::STAGES) cb -= S::STAGES;
-        if (tile_of(k0 + tsub) < tiles) consume(tile_of(k0 + tsub), cb);
-      });
+      if constexpr (S::K64) {
+        static_assert(S::TPI % 2 == 0, "the K = 64 form consumes pairs of tiles");
+        static_for<S::TPI / 2>([&](auto t_c) {
+          constexpr int tsub = 2 * decltype(t_c)::value;
+          int cb0 = buf + tsub;
+          if (cb0 >= S::STAGES) cb0 -= S::STAGES;
+          const int cb1 = (cb0 + 1 == S::STAGES) ? 0 : cb0 + 1;
+          if (tile_of(k0 + tsub) < tiles) consume_pair_s8(tile_of(k0 + tsub), cb0, tile_of(k0 + tsub + 1), cb1);
+        });
+      } else {
+        static_for<S::TPI>([&](auto t_c) {
+          constexpr int tsub = decltype(t_c)::value;
+          int cb = buf + tsub;
+          if (cb >= S::STAGES) cb -= S::STAGES;
+          if (tile_of(k0 + tsub) < tiles) consume(tile_of(k0 + tsub), cb);
+        });
+      }
       buf += S::TPI;
       if (buf >= S::STAGES) buf -= S::STAGES;
     }
@@ -1105,6 +1249,12 @@ static int wg_shape_pieces_s8(int shape) {
 #undef X
   return 0;
 }
+static int wg_shape_cost_s8(int shape) {
+#define X(id, a, b, c, d) if (shape == id) return WgShape<a, b, c, d, true>::COST;
+  DN_WG_SHAPES(X)
+#undef X
+  return 0;
+}
 
 __device__ __forceinline__ void weight_grad_dispatch_f32(const WgParams& p, int wg, int n_wg, char* smem) {
   switch (p.shape) {
@@ -1290,13 +1440,14 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
     if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out, 4, x_slot, W, 0, h_dW[u], W, h_db[u], &b.u[u], s8))) return rc;
     ++u;
   }
-  // divide the workgroups (one per CU) among the units in proportion to the pieces each streams (largest remainder)
+  // divide the workgroups (one per CU) among the units in proportion to the pieces each streams - the 8-bit kernel: to the cycles a
+  // tile costs, WgShape::COST - (largest remainder)
   const long long tiles = (n_points + 31) / 32;
   int total_wg = device_cus();
   if (total_wg < n_units) total_wg = n_units;
   long long cost[kWgMaxUnits], cost_sum = 0;
   for (int i = 0; i < n_units; ++i) {
-    cost[i] = f32 ? wg_shape_pieces_f32(b.u[i].shape) : (s8 ? wg_shape_pieces_s8(b.u[i].shape) : wg_shape_pieces(b.u[i].shape));
+    cost[i] = f32 ? wg_shape_pieces_f32(b.u[i].shape) : (s8 ? wg_shape_cost_s8(b.u[i].shape) : wg_shape_pieces(b.u[i].shape));
     cost_sum += cost[i];
   }
   int share[kWgMaxUnits], given = 0;

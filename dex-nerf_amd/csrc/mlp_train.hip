@@ -546,7 +546,7 @@ struct WgShape {
   static constexpr int PER_WAVE = (PIECES + 7) / 8;        // DMAs per tile of the busiest wave
   // 8-bit kernel: PAIRS of tiles contracted by the K = 64 fp8 MFMA (twice the K = 16 rate) wherever 24 operand registers fit
   // beside the accumulators (J <= 9: all but the skip layer of a W = 256 net, which keeps the K = 16 form)
-  static constexpr bool K64 = S8 && J <= 9;
+  static constexpr bool K64 = S8 && J <= 11;
   // tiles per barrier: by the MFMA count of a tile, not by its bytes
   static constexpr int TPI0 = wg_tiles_per_iter(S8 ? 2 * PIECES : PIECES);
   static constexpr int TPI = (K64 && TPI0 < 2) ? 2 : TPI0;
@@ -786,18 +786,31 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
     };
     // two k-tiles' operands ahead of the MFMA that uses them (the LDS round trip of four transposing reads is longer than one
     // 16-pass MFMA), and no further: left alone the scheduler hoists all J x 8 operand registers above the first MFMA
-    i32x8 bq0 = load_b(std::integral_constant<int, 0>{});
-    i32x8 bq1 = bq0;
-    if constexpr (S::J > 1) bq1 = load_b(std::integral_constant<int, (S::J > 1 ? 1 : 0)>{});
-    static_for<S::J>([&](auto j_c) {
-      constexpr int j = decltype(j_c)::value;
-      i32x8 bnew = bq1;
-      if constexpr (j + 2 < S::J) bnew = load_b(std::integral_constant<int, (j + 2 < S::J ? j + 2 : 0)>{});
-      acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bq0, acc[j], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      bq0 = bq1;
-      bq1 = bnew;
-    });
+    // (the widest layer, 11 accumulator tiles, has room for ONE operand set ahead)
+    if constexpr (S::J > 9) {
+      i32x8 bcur = load_b(std::integral_constant<int, 0>{});
+      static_for<S::J>([&](auto j_c) {
+        constexpr int j = decltype(j_c)::value;
+        i32x8 bnext = bcur;
+        if constexpr (j + 1 < S::J) bnext = load_b(std::integral_constant<int, (j + 1 < S::J ? j + 1 : 0)>{});
+        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bcur, acc[j], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bcur = bnext;
+      });
+    } else {
+      i32x8 bq0 = load_b(std::integral_constant<int, 0>{});
+      i32x8 bq1 = bq0;
+      if constexpr (S::J > 1) bq1 = load_b(std::integral_constant<int, (S::J > 1 ? 1 : 0)>{});
+      static_for<S::J>([&](auto j_c) {
+        constexpr int j = decltype(j_c)::value;
+        i32x8 bnew = bq1;
+        if constexpr (j + 2 < S::J) bnew = load_b(std::integral_constant<int, (j + 2 < S::J ? j + 2 : 0)>{});
+        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bq0, acc[j], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bq0 = bq1;
+        bq1 = bnew;
+      });
+    }
   };
   // 8-bit buffers, one tile, K = 16 MFMAs: the shapes whose accumulators leave no room for the K = 64 operands (S::K64 false)
   auto consume_s8 = [&](long long tile, int cb) {

@@ -516,13 +516,17 @@ struct WgParams {
 };
 
 constexpr int kWgLdsBytes = 144 * 1024;
+// bf16 weight-gradient kernel: pieces are staged 1088 bytes apart (64 B more than their size), so that the two pieces of a pair sit on
+// different halves of the 32 LDS banks (see weight_grad_unit), and its tile buffers may use 158 KiB
+constexpr int kWgPieceStride16 = kPieceBytes + 64;
+constexpr int kWgLdsBytes16 = 158 * 1024;
 
 // Tiles consumed per barrier: a small tile (few pieces) is a few MFMAs per wave, so the barrier + wait + LDS latency of
 // an iteration is amortised over 2 or 4 of them (the as-shipped 4x128 nets are all "small").
 constexpr int wg_tiles_per_iter(int pieces) { return pieces <= 12 ? 4 : (pieces <= 24 ? 2 : 1); }
 
-constexpr int wg_stages_for(int pieces, int tpi) {
-  int s = kWgLdsBytes / (pieces * kPieceBytes);
+constexpr int wg_stages_for(int pieces, int tpi, bool s8) {
+  int s = s8 ? kWgLdsBytes / (pieces * kPieceBytes) : kWgLdsBytes16 / (pieces * kWgPieceStride16);
   if (s > 16) s = 16;
   const int per_wave = (pieces + 7) / 8;
   while (s > 2 * tpi && (s - 2 * tpi) * per_wave > 48) --s;  // counted-wait range
@@ -550,7 +554,8 @@ struct WgShape {
   // tiles per barrier: by the MFMA count of a tile, not by its bytes
   static constexpr int TPI0 = wg_tiles_per_iter(S8 ? 2 * PIECES : PIECES);
   static constexpr int TPI = (K64 && TPI0 < 2) ? 2 : TPI0;
-  static constexpr int STAGES = wg_stages_for(PIECES, TPI); // tile buffers in LDS; STAGES - TPI tiles in flight
+  static constexpr int STAGES = wg_stages_for(PIECES, TPI, S8); // tile buffers in LDS; STAGES - TPI tiles in flight
+  static constexpr int PSTRIDE = S8 ? kPieceBytes : kWgPieceStride16;   // LDS distance of consecutive staged pieces
   // Cycles one 32-point tile costs a workgroup of this shape in the 8-bit kernel, fitted to -DDN_WG_STAMP runs (profiles/r02_train_s8.md;
   // measured / model for the W = 256 shapes: (8,0,2) 678 / 746, (8,8,0) 1131 / 1134, (4,8,1) 940 / 1000, (1,8,0) 868 / 904, (8,8,2)
   // 2123 / 2138): wait + barrier, ~100 issue cycles per LDS-DMA of the busiest wave, and the MFMAs of the two waves of a SIMD - K = 64:
@@ -558,7 +563,7 @@ struct WgShape {
   // The 8-bit launch divides its workgroups among the layers by this, not by bytes: it is not HBM-bound.
   static constexpr int COST = K64 ? 250 + 12 * J + 100 * PER_WAVE + (64 * J > 260 ? 64 * J : 260) + (KGROUPS > 1 ? 170 : 0) - (TPI >= 4 ? 100 : 0)
                                   : 430 / TPI + 100 * PER_WAVE + 128 * J;
-  static_assert(STAGES >= 2 * TPI && STAGES * PIECES * kPieceBytes <= 160 * 1024, "LDS budget");
+  static_assert(STAGES >= 2 * TPI && STAGES * PIECES * PSTRIDE <= 160 * 1024, "LDS budget");
   static_assert(XT + PET >= 1 && NTN * KGROUPS == 8, "shape");
 };
 
@@ -602,7 +607,8 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
   if (wg >= tiles) return;  // nothing to add (workgroup-uniform)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int BUF = S::PIECES * kPieceBytes;
+  constexpr int BUF = S::PIECES * S::PSTRIDE;
+  constexpr int PS = S::PSTRIDE;
 
   // wave -> (n-tile, subset of k-tiles)
   const int ntile = wave % S::NTN;
@@ -617,8 +623,13 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
   // bf16 form has to, puts a group's chunk pairs 512 bytes apart = on the same bank: PMC showed one conflict cycle per two
   // LDS cycles.  The price is a permuted feature order inside the 32-wide tile: s8_feature below.)
   // (the 8-bit kernel's MFMA contracts 64 points = a PAIR of tiles: hh selects the tile, the four reads of a lane its 32 points)
+  // bf16 pieces: a 16-lane group reads 4 rows x 32 bytes = [16 bytes of piece 2t | 16 bytes of piece 2t+1] of the lanes (point, lane
+  // half fs) - the same pairing as the 8-bit units - and pieces are staged 1088 bytes apart, so the two 16-byte halves of a row sit 64
+  // bytes apart modulo the 128-byte bank period: a group covers all 32 banks once.  (Reading the two lane halves of ONE piece side by
+  // side put them 512 B apart = on the same 16 banks: stamps showed 2,242 cycles of `consume` per 256 x 256 tile for 1,152 cycles
+  // of MFMAs, PMC three conflict cycles in four LDS cycles.)
   const int lane_off = S::S8 ? ((fs * 32 + (li >> 1)) * 16) + (li & 1) * 8
-                             : ((((li & 3) >> 1) * 32 + (li >> 2) + 8 * hh) * 16) + ((li & 3) & 1) * 8;
+                             : ((li & 3) >> 1) * PS + ((fs * 32 + (li >> 2) + 8 * hh) * 16) + ((li & 3) & 1) * 8;
 
   // ---- staging: each 1 KiB piece is one LDS-DMA (opaque asm: the counted waits below are ours; hipcc would drain
   // with vmcnt(0) at every barrier).  This wave stages pieces wave, wave + 8, ... of every tile.
@@ -641,7 +652,7 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
       const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(src_bits));
       const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(src_bits >> 32));
       const char* usrc = reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
-      const unsigned lds = __builtin_amdgcn_readfirstlane(smem_addr + buf * BUF + (wave + 8 * e) * kPieceBytes);
+      const unsigned lds = __builtin_amdgcn_readfirstlane(smem_addr + buf * BUF + (wave + 8 * e) * PS);
       const unsigned go = __builtin_amdgcn_readfirstlane((wave + 8 * e < S::PIECES) ? 1u : 0u);
       const unsigned voff = lane16;  // (asm operands do not capture: name a local)
       unsigned keep;
@@ -683,14 +694,14 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
   // one staged tile: A = dY^T fragments of this wave's n-tile, B = the X / PE / all-ones k-tiles, 2 MFMAs per k-tile
   auto consume_16 = [&](long long tile, int cb) {
     const char* base = smem + cb * BUF + lane_off;
-    // A = dY^T fragments of this wave's n-tile, two 16-point k-steps
-    // (a custom dY has a single piece: the fs=1 lane groups re-read it and are zeroed)
-    const int dy_piece = S::CUSTOM ? 0 : 2 * ntile + fs;
-    bf16x8 a0 = tr_frag(base + dy_piece * kPieceBytes, 0);
-    bf16x8 a1 = tr_frag(base + dy_piece * kPieceBytes, 16);
+    // A = dY^T fragments of this wave's n-tile, two 16-point k-steps (fragment row 16 fs + li = piece li >> 3 of the pair, lane half fs,
+    // element li & 7).  A custom dY is a single piece: the columns read from its neighbour are zeroed.
+    const char* dy = base + (S::CUSTOM ? 0 : 2 * ntile) * PS;
+    bf16x8 a0 = tr_frag(dy, 0);
+    bf16x8 a1 = tr_frag(dy, 16);
     if constexpr (S::CUSTOM) {
-      a0 = fs ? zeros : a0;
-      a1 = fs ? zeros : a1;
+      a0 = (li >> 3) ? zeros : a0;
+      a1 = (li >> 3) ? zeros : a1;
     }
     const long long valid = p.n_points - tile * 32;  // points of this tile that exist (the rest are padding copies)
     if (valid < 32) {
@@ -707,7 +718,7 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
         if constexpr (j == S::KT - 1) { b0 = ones; b1 = ones; }
         else {
 #ifndef DN_WG_NOREAD
-          const char* pb = base + (S::N_DY + 2 * j) * kPieceBytes + fs * kPieceBytes;
+          const char* pb = base + (S::N_DY + 2 * j) * PS;
           b0 = tr_frag(pb, 0);
           b1 = tr_frag(pb, 16);
 #else
@@ -717,7 +728,7 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
       } else {
         const int kt = kgroup + j * S::KGROUPS;           // wave-uniform; kt >= KT: an unused accumulator
         const int ktr = kt < S::KT - 1 ? kt : S::KT - 2;  // a piece that exists
-        const char* pb = base + (S::N_DY + 2 * ktr) * kPieceBytes + fs * kPieceBytes;
+        const char* pb = base + (S::N_DY + 2 * ktr) * PS;
         b0 = tr_frag(pb, 0);
         b1 = tr_frag(pb, 16);
         const bool is_ones = kt >= S::KT - 1;
@@ -1007,10 +1018,9 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
     constexpr int j = decltype(j_c)::value;
     const int kt = kgroup + j * S::KGROUPS;
     if (kt < S::KT) {
-      // fragment row / column i (0..31) = (piece s of the tile's two, lane half h, element e): bf16 reads i = 16 s + 8 h + e,
-      // the 8-bit reads i = 16 h + 8 s + e (see lane_off)
-      auto piece_of = [](int i) { return S::S8 ? (i >> 3) & 1 : i >> 4; };
-      auto half_of = [](int i) { return S::S8 ? i >> 4 : (i >> 3) & 1; };
+      // fragment row / column i (0..31) = (piece s of the tile's two, lane half h, element e): i = 16 h + 8 s + e (see lane_off)
+      auto piece_of = [](int i) { return (i >> 3) & 1; };
+      auto half_of = [](int i) { return i >> 4; };
       auto feature_of = [&](int i) { return acc_row(piece_of(i) * 8 + (i & 7), half_of(i)); };
       int col;
       if (kt < S::XT) col = 32 * kt + feature_of(jl);
@@ -1024,8 +1034,8 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
         const int irow = acc_row(r, half);
         int n = 32 * ntile + feature_of(irow);
         if constexpr (S::CUSTOM) {
-          // custom piece: row = 8h + e (bf16: the tile's piece 0; 8-bit: piece dy_odd of the unit - the other one was zeroed)
-          const bool mine = S::S8 ? piece_of(irow) == p.dy_odd : irow < 16;
+          // custom piece: row = 8h + e (bf16: piece 0 of the pair read; 8-bit: piece dy_odd of the unit - the other one was zeroed)
+          const bool mine = piece_of(irow) == (S::S8 ? p.dy_odd : 0);
           n = mine ? half_of(irow) * 8 + (irow & 7) : p.custom_rows;
           if (n >= p.custom_rows) continue;
         }
@@ -1229,7 +1239,7 @@ static int wg_shape_pieces(int shape) {
   return 0;
 }
 static int wg_shape_lds(int shape) {
-#define X(id, a, b, c, d) if (shape == id) return WgShape<a, b, c, d>::STAGES * WgShape<a, b, c, d>::PIECES * kPieceBytes;
+#define X(id, a, b, c, d) if (shape == id) return WgShape<a, b, c, d>::STAGES * WgShape<a, b, c, d>::PIECES * WgShape<a, b, c, d>::PSTRIDE;
   DN_WG_SHAPES(X)
 #undef X
   return 0;
@@ -1496,7 +1506,7 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
     hipLaunchKernelGGL(weight_grad_batch_kernel_f32, dim3(static_cast<unsigned>(b.wg_begin[n_units])), dim3(512), 158 * 1024,
                        as_stream(stream), b);
   else
-    hipLaunchKernelGGL(weight_grad_batch_kernel, dim3(static_cast<unsigned>(b.wg_begin[n_units])), dim3(512), kWgLdsBytes,
+    hipLaunchKernelGGL(weight_grad_batch_kernel, dim3(static_cast<unsigned>(b.wg_begin[n_units])), dim3(512), kWgLdsBytes16,
                        as_stream(stream), b);
 #ifdef DN_WG_STAMP
   {

@@ -401,10 +401,11 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(REPO, "dex-nerf_amd"))
                 import train_dexnerf
-                res = train_dexnerf.main(["--iters", "4000", "--size", "64", "--views", "8", "--num-random-rays", "1024", "--layers", "4",
-                                          "--width", "128", "--num-fine", "64", "--validate-every", "0", "--quiet", "--precision", "bf16"])
-                result["train_as_shipped"] = {"rays_per_s": res["rays_per_s"], "rays_per_step": 1024,
-                                              "what": "train_dexnerf.py, 4x128 nets, 64+64 samples, HIP-graph replay, incl. capture time"}
+                for key, prec in (("train_as_shipped", "bf16"), ("train_as_shipped_s8_mode", "bf16-s8")):
+                    res = train_dexnerf.main(["--iters", "4000", "--size", "64", "--views", "8", "--num-random-rays", "1024", "--layers", "4",
+                                              "--width", "128", "--num-fine", "64", "--validate-every", "0", "--quiet", "--precision", prec])
+                    result[key] = {"rays_per_s": res["rays_per_s"], "rays_per_step": 1024, "final_train_psnr_db": res["history"][-1][2],
+                                   "what": f"train_dexnerf.py --precision {prec}, 4x128 nets, 64+64 samples, HIP-graph replay, incl. capture time"}
             except Exception as exc:  # noqa: BLE001
                 result["train_as_shipped"] = {"error": f"{type(exc).__name__}: {exc}"}
             finally:

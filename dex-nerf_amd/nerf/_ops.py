@@ -41,7 +41,10 @@ def train_precision(packed):
 
 
 def set_s8_grad_scale(scale):
-    """Power of two the saved layer gradients are multiplied by before they are rounded to e5m2 (default 65536)."""
+    """Power of two the saved layer gradients are multiplied by before they are rounded to e5m2 (default 65536 = 2^16).
+    With it, per-point gradients dL/d(pre-activation) between 2.3e-10 (e5m2's smallest subnormal / 2^16; smaller ones flush to
+    zero) and 0.87 (57344 / 2^16; larger ones saturate) are representable, 2 mantissa bits each: the range of a mean-reduced MSE
+    loss over 10^3 .. 10^5 rays from the first iteration to > 40 dB.  A sum-reduced loss, or loss scaling, wants a smaller scale."""
     check(lib().dn_set_s8_grad_scale(float(scale)), "dn_set_s8_grad_scale")
 
 

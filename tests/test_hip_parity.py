@@ -1215,7 +1215,7 @@ def test_config4_full_size_render_properties_bf16(dev):
     assert psnr > 38.0
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16-s8"])
 def test_one_call_training_path_equals_stage_composition(golden, dev, precision, monkeypatch):
     """predict_and_render_radiance under autograd as ONE C-ABI call forward
     (dn_render_rays_train) and one backward (dn_render_rays_backward), against the stage-by-stage Python composition of the

@@ -34,7 +34,7 @@ def make_cfg(args):
     def mode(train):
         return dict(chunksize=args.chunksize, lindisp=False, num_coarse=args.num_coarse, num_fine=args.num_fine,
                     perturb=train, radiance_field_noise_std=args.noise_std if train else 0.0, white_background=False)
-    return nerf.CfgNode(dict(dataset=dict(near=args.near, far=args.far, no_ndc=True),
+    return nerf.CfgNode(dict(dataset=dict(near=args.near, far=args.far, no_ndc=not getattr(args, "ndc", False)),
                              nerf=dict(use_viewdirs=True, train=mode(True), validation=mode(False))))
 
 
@@ -94,6 +94,28 @@ def messytable_dataset(args, dev):
                 train=[int(i) for i in i_split[0]], val=val, mask_hi=1.25)
 
 
+def llff_dataset(args, dev):
+    """A forward-facing capture in the LLFF layout (nerf/llff.py; reference nerf/load_llff.py + the LLFF branch of
+    train_nerf_rgb.py:70-95): camera-to-world poses in NeRF's (right, up, back) frame with a shared pinhole (f, W/2, H/2).
+    The kernels take the fork's convention - a world-to-camera extrinsic in OpenCV axes plus a 3x3 K (nerf_helpers.py:67-112:
+    dir = [(i-cx)/fx, (j-cy)/fx, 1], rd = inv(E[:3,:3]) dir, ro = inv(E)[:3,3]) - so E = inv([R diag(1,-1,-1) | t])."""
+    images, poses, bds, _, i_test = nerf.load_llff_data(args.llff, factor=args.llff_factor)
+    h, w, f = int(poses[0, 0, 4]), int(poses[0, 1, 4]), float(poses[0, 2, 4])
+    k_mat = torch.tensor([[f, 0.0, w * 0.5], [0.0, f, h * 0.5], [0.0, 0.0, 1.0]], dtype=torch.float32, device=dev)
+    flip = np.diag([1.0, -1.0, -1.0])
+    extr = []
+    for c2w in poses[:, :3, :4].astype(np.float64):
+        m = np.eye(4)
+        m[:3, :3], m[:3, 3] = c2w[:, :3] @ flip, c2w[:, 3]
+        extr.append(torch.from_numpy(np.linalg.inv(m).astype(np.float32)).to(dev))
+    n = images.shape[0]
+    hold = list(range(n))[::args.llffhold] if args.llffhold > 0 else [int(i_test)]
+    train = [i for i in range(n) if i not in hold] or [int(i_test)]
+    return dict(hw=(h, w), poses=extr, intrinsics=[k_mat] * n, images=[torch.from_numpy(images[i].reshape(-1, 3)).to(dev) for i in range(n)],
+                depths=[None] * n, train=train, val=hold[0], mask_hi=None, focal=f,
+                bounds=(float(bds.min()) * 0.9, float(bds.max()) * 1.0))
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=2000)
@@ -120,6 +142,11 @@ def main(argv=None):
     ap.add_argument("--load-checkpoint", default="")
     ap.add_argument("--messytable", default="", help="train on a scene directory in the reference's MessyTable / Dex-NeRF "
                                                      "layout instead of the built-in synthetic scene")
+    ap.add_argument("--llff", default="", help="train on a forward-facing capture in the LLFF layout (poses_bounds.npy + images[_N]/); "
+                                               "rays are warped to NDC like the reference's LLFF configs unless --no-ndc")
+    ap.add_argument("--llff-factor", type=int, default=8, help="image downsampling factor (images_<factor>/; the reference default)")
+    ap.add_argument("--llffhold", type=int, default=8, help="every N-th view is held out (0: only the view nearest the average pose)")
+    ap.add_argument("--no-ndc", action="store_true", help="LLFF: keep world-space rays with the capture's depth bounds")
     ap.add_argument("--imgname", default="0128_irL_kuafu_half.png")
     ap.add_argument("--real-rgb", action="store_true")
     ap.add_argument("--near", type=float, default=None, help="default 2 (synthetic scene) / 0.3 (MessyTable)")
@@ -129,6 +156,10 @@ def main(argv=None):
                     help="launch every kernel of an iteration from Python instead of replaying one captured HIP graph "
                          "(single-GPU runs capture by default: the as-shipped 4x128 nets at 1024 rays are launch-bound)")
     args = ap.parse_args(argv)
+    user_bounds = args.near is not None or args.far is not None
+    args.ndc = bool(args.llff) and not args.no_ndc
+    if args.ndc:
+        args.near, args.far = 0.0, 1.0        # the NDC cube (the reference's LLFF configs)
     if args.near is None:
         args.near = 0.3 if args.messytable else 2.0
     if args.far is None:
@@ -155,7 +186,13 @@ def main(argv=None):
     cfg = make_cfg(args)
     ex, ed = nerf.get_embedding_function(10, True, True), nerf.get_embedding_function(4, True, True)
     thres = np.arange(5, args.m_thres + 5, 5)
-    data = messytable_dataset(args, dev) if args.messytable else synthetic_dataset(args, kw, cfg, ex, ed, thres, dev)
+    if args.llff:
+        data = llff_dataset(args, dev)
+        if not args.ndc and not user_bounds:      # world-space rays: the capture's own depth bounds
+            args.near, args.far = data["bounds"]
+            cfg.dataset.near, cfg.dataset.far = data["bounds"]
+    else:
+        data = messytable_dataset(args, dev) if args.messytable else synthetic_dataset(args, kw, cfg, ex, ed, thres, dev)
     hw, poses, intrinsics, images, depths = data["hw"], data["poses"], data["intrinsics"], data["images"], data["depths"]
     held_out = data["val"]
 
@@ -188,6 +225,11 @@ def main(argv=None):
     def iteration():
         """select rays -> coarse + fine render -> loss -> backward -> (all-reduce) -> Adam; device-side state only."""
         rays, target = selector.select(selector.random_pixels(args.num_random_rays))
+        if args.ndc:
+            # run_one_iter_of_nerf's NDC branch (reference train_utils.py:240-262) on the selected rows: origins / directions
+            # through dn_ndc_rays (near plane at 1), bounds 0 .. 1, view directions stay those of the unwarped rays
+            ro, rd = nerf.ndc_rays(hw[0], hw[1], data["focal"], 1.0, rays[:, :3].contiguous(), rays[:, 3:6].contiguous())
+            rays = torch.cat([ro, rd, rays[:, 6:]], dim=-1)
         chunks = [nerf.predict_and_render_radiance(batch, student[0], student[1], cfg, mode="train", encode_position_fn=ex,
                                                    encode_direction_fn=ed, m_thres_cand=thres)
                   for batch in nerf.get_minibatches(rays, chunksize=args.chunksize)]
@@ -242,6 +284,10 @@ def main(argv=None):
         if rank == 0 and args.validate_every and (it + 1) % args.validate_every == 0:
             out = render_view(student, cfg, poses[held_out], intrinsics[held_out], hw, ex, ed, thres)
             vmse = nerf.img2mse(out[3].reshape(-1, 3), images[held_out]).item()
+            if depths[held_out] is None:     # (LLFF captures carry no depth maps: no Dex threshold sweep)
+                if not args.quiet:
+                    print(f"[val]   iter {it + 1:6d} held-out view psnr {nerf.mse2psnr(vmse):.2f} dB", flush=True)
+                continue
             m_best, err = dex_sweep(out, depths[held_out], thres, data["mask_hi"])
             if not args.quiet:
                 print(f"[val]   iter {it + 1:6d} held-out view psnr {nerf.mse2psnr(vmse):.2f} dB; Dex best m={m_best} "
@@ -255,8 +301,9 @@ def main(argv=None):
     if rank == 0:
         out = render_view(student, cfg, poses[held_out], intrinsics[held_out], hw, ex, ed, thres)
         result["val_psnr"] = nerf.mse2psnr(nerf.img2mse(out[3].reshape(-1, 3), images[held_out]).item())
-        m_best, err = dex_sweep(out, depths[held_out], thres, data["mask_hi"])
-        result["dex_best_threshold"], result["dex_abs_err_mm"] = int(m_best), err["depth_abs_err"]
+        if depths[held_out] is not None:
+            m_best, err = dex_sweep(out, depths[held_out], thres, data["mask_hi"])
+            result["dex_best_threshold"], result["dex_abs_err_mm"] = int(m_best), err["depth_abs_err"]
         if args.save:
             opt_state = opt.state_dict()
             for group in opt_state["param_groups"]:   # the reference stores a Python float (train_dexnerf_rgb.py:443-456), not the

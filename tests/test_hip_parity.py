@@ -1493,3 +1493,46 @@ def test_llff_capture_renders_through_the_ndc_branch(dev, tmp_path):
     depth = C(out[4])
     assert depth.min() >= 0.0 and depth.max() <= 1.0 + 1e-6          # NDC depths live in [0, 1]
     assert 0.0 <= float(C(out[5]).min()) and float(C(out[5]).max()) <= 1.0 + 1e-5
+
+
+def test_training_from_an_llff_capture(dev, tmp_path):
+    """N2 + S2b + N1 end to end: a forward-facing capture of the built-in teacher scene written in the LLFF layout (poses_bounds.npy in
+    LLFF's (down, right, back) axes + images/) -> nerf.load_llff_data -> train_dexnerf.py --llff: NDC rays through dn_ndc_rays inside
+    the (HIP-graph-captured) iteration, validation through run_one_iter_of_nerf's NDC branch.  The student must learn (+6 dB)."""
+    import nerf
+    import train_dexnerf
+    from PIL import Image
+    from nerf import synthetic as syn
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "images"))
+    h = w = 48
+    f = 60.0
+    mkw = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+    teacher = make_models(mkw, syn.synth_state_dict(42, sigma_bias=-150.0, **mkw), syn.synth_state_dict(43, sigma_bias=-20.0, **mkw), dev)
+    cfg = make_cfg(dict(num_coarse=64, num_fine=64, near=2.0, far=6.0))
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    rows = []
+    k = 0
+    for y in (-0.5, 0.0, 0.5):
+        for x in (-0.6, -0.2, 0.2, 0.6):
+            c2w = np.eye(4, dtype=np.float32)
+            c2w[:3, 3] = [x, y, 4.0]                                   # looking down -z at the scene around the origin
+            ro, rd = nerf.get_ray_bundle(h, w, f, torch.from_numpy(c2w).to(dev))
+            with torch.no_grad():
+                out = nerf.run_one_iter_of_nerf(h, w, f, teacher[0], teacher[1], ro, rd, cfg, mode="validation", encode_position_fn=ex,
+                                                encode_direction_fn=ed, m_thres_cand=M_THRES)
+            img = (C(out[3]).clip(0, 1) * 255 + 0.5).astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(root, "images", f"{k:02d}.png"))
+            block = np.stack([-c2w[:3, 1], c2w[:3, 0], c2w[:3, 2], c2w[:3, 3], np.array([h, w, f], dtype=np.float32)], axis=1)
+            rows.append(np.concatenate([block.reshape(-1), [2.0, 6.0]]))
+            k += 1
+    np.save(os.path.join(root, "poses_bounds.npy"), np.stack(rows).astype(np.float64))
+    try:
+        res = train_dexnerf.main(["--llff", root, "--llff-factor", "1", "--llffhold", "6", "--iters", "300", "--num-random-rays", "512",
+                                  "--layers", "4", "--width", "128", "--num-fine", "64", "--validate-every", "0", "--quiet",
+                                  "--precision", "bf16"])
+    finally:
+        nerf.set_precision("fp32")
+    first, last = res["history"][0], res["history"][-1]
+    assert np.isfinite(last[1]) and last[2] - first[2] > 6.0, (first, last)
+    assert res["val_psnr"] > 12.0 and "dex_best_threshold" not in res

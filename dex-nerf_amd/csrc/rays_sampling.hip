@@ -358,6 +358,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(const float* __restrict__ 
       int sc[kMergeCoarse], sf[kMergeFine];
 #pragma unroll
       for (int e = 0; e < kMergeCoarse; ++e) {        // coarse depth i: samples strictly in front of it
+        if (64 * e >= nc) { vc[e] = 0.0f; sc[e] = 0; continue; }   // (wave-uniform: no search for rows that do not exist)
         const int i = lane + 64 * e;
         const float v = sbuf[min(i, nc - 1)];
         int lo = 0, hi = nf;
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(const float* __restrict__ 
       }
 #pragma unroll
       for (int e = 0; e < kMergeFine; ++e) {          // sample q: coarse depths in front of it or equal to it
+        if (64 * e >= nf) { vf[e] = 0.0f; sf[e] = 0; continue; }
         const int q = lane + 64 * e;
         const float v = zs[min(q, nf - 1)];
         int lo = 0, hi = nc;

@@ -174,7 +174,7 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pos
     # once by the forward / backward chains and read once by the weight-gradient kernel; MFMA rate beside it (3x forward FLOP)
     nbytes = 0
     for m, s in ((models[0], NC), (models[1], NC + NF)):
-        a, mk, g = _ops.train_sizes(m.packed(), n_rays * s, prec=_ops.train_precision(m.packed()))
+        a, mk, g = _ops.train_sizes(m.packed(train=True), n_rays * s, prec=_ops.train_precision(m.packed(train=True)))
         nbytes += 2 * (a + g) + 2 * mk + n_rays * s * (16 + 16 + 4) * 2   # + rf / g_rf / z through compositing
     flops = 3.0 * n_rays * POINTS_PER_RAY * FLOP_PER_POINT
     res["roofline"] = {"bound": "hbm", "achieved": nbytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / dt / 8e12,

@@ -577,9 +577,15 @@ extern "C" size_t dn_mlp_packed_bytes(const dn_mlp_desc* desc, int precision) {
 
 extern "C" int dn_mlp_pack(const dn_mlp_desc* desc, int precision, const float* const* h_weights,
                            const float* const* h_biases, void* packed, dn_stream_t stream) {
+  return dn_mlp_pack_parts(desc, precision, h_weights, h_biases, packed, DN_PACK_ALL, stream);
+}
+
+extern "C" int dn_mlp_pack_parts(const dn_mlp_desc* desc, int precision, const float* const* h_weights,
+                                 const float* const* h_biases, void* packed, int parts, dn_stream_t stream) {
   int rc = validate_desc(desc, precision);
   if (rc) return rc;
   DN_REQUIRE(h_weights && h_biases && packed, "dn_mlp_pack: NULL pointer");
+  DN_REQUIRE(parts != 0 && (parts & ~DN_PACK_ALL) == 0, "dn_mlp_pack_parts: parts must be a non-empty mask of DN_PACK_CORE | DN_PACK_G48");
   DN_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "dn_mlp_pack: packed buffer must be 16-byte aligned");
   NetLayout L;
   build_layout(*desc, precision, &L);
@@ -590,8 +596,8 @@ extern "C" int dn_mlp_pack(const dn_mlp_desc* desc, int precision, const float* 
     ptrs.w[i] = h_weights[i];
     ptrs.b[i] = h_biases[i];
   }
-  rc = launch_pack(L, ptrs, packed, precision, as_stream(stream));
-  if (rc == 0 && g48_supported(*desc, precision))
+  if (parts & DN_PACK_CORE) rc = launch_pack(L, ptrs, packed, precision, as_stream(stream));
+  if (rc == 0 && (parts & DN_PACK_G48) && g48_supported(*desc, precision))
     rc = launch_pack48(*desc, precision, ptrs, static_cast<char*>(packed) + L.bias_bytes + static_cast<size_t>(L.total_pieces) * kPieceBytes,
                        as_stream(stream));
   return rc;

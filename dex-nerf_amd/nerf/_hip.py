@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("DEXNERF_HIP_LIB", os.path.join(os.path.dirname(_HERE)
 PREC_F32 = 0
 PREC_BF16 = 1
 PREC_F16 = 2
+PACK_CORE, PACK_G48, PACK_ALL = 1, 2, 3   # dn_mlp_pack_parts: the streams of a packed buffer
 PREC_BF16_S8 = 3   # training entry points: bf16 arithmetic, 8-bit saved activations / gradients (experimental)
 
 EXPORTS = (
@@ -26,7 +27,7 @@ EXPORTS = (
     "dn_mlp_backward_data", "dn_mlp_unpack", "dn_mlp_weight_grad", "dn_mlp_weight_grad_all",
     "dn_select_rays", "dn_select_rays_indirect", "dn_ndc_rays", "dn_dex_error_sweep", "dn_depth_error_image",
     "dn_render_train_workspace_bytes", "dn_render_rays_train", "dn_render_rays_backward",
-    "dn_set_s8_grad_scale", "dn_mlp_convert_saved_s8",
+    "dn_set_s8_grad_scale", "dn_mlp_convert_saved_s8", "dn_mlp_pack_parts",
 )
 
 
@@ -50,6 +51,7 @@ def _declare(lib):
     lib.dn_mlp_packed_bytes.argtypes = [POINTER(MlpDesc), c_int]
     lib.dn_mlp_packed_bytes.restype = c_size_t
     lib.dn_mlp_pack.argtypes = [POINTER(MlpDesc), c_int, POINTER(c_void_p), POINTER(c_void_p), vp, vp]
+    lib.dn_mlp_pack_parts.argtypes = [POINTER(MlpDesc), c_int, POINTER(c_void_p), POINTER(c_void_p), vp, c_int, vp]
     lib.dn_run_network.argtypes = [POINTER(MlpDesc), c_int, vp, fp, fp, fp, c_int, fp, c_int64, c_int, fp, vp]
     lib.dn_mlp_forward_encoded.argtypes = [POINTER(MlpDesc), c_int, vp, fp, c_int64, fp, vp]
     lib.dn_volume_render.argtypes = [fp, fp, fp, c_int, fp, c_float, c_int, POINTER(c_float), c_int, c_int64, c_int,

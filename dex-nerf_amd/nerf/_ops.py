@@ -157,18 +157,20 @@ class PackedMLP:
         if nbytes == 0:
             check(-1001, "dn_mlp_packed_bytes")
         self.buffer = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        self.key = None
+        self.key = None          # parameter key the core stream (bias tiles + pieces: every kernel but one) was packed from
+        self.key48 = None        # ... and the stream of the 48-point inference kernel: a training loop leaves it stale until a render
         self.buffer_bwd = None   # transposed stream for the backward-data chain, packed on first training use
         self.key_bwd = None
 
-    def pack(self, weights, biases):
-        """weights/biases: lists of device tensors in the reference parameter order."""
+    def pack(self, weights, biases, parts=_hip.PACK_ALL):
+        """weights/biases: lists of device tensors in the reference parameter order; parts: _hip.PACK_CORE | _hip.PACK_G48."""
         n = len(weights)
         ws = [f32c(w.detach()) for w in weights]
         bs = [f32c(b.detach()) for b in biases]
         wp = (c_void_p * n)(*[w.data_ptr() for w in ws])
         bp = (c_void_p * n)(*[b.data_ptr() for b in bs])
-        check(lib().dn_mlp_pack(ctypes.byref(self.desc), self.precision, wp, bp, ptr(self.buffer), stream()), "dn_mlp_pack")
+        check(lib().dn_mlp_pack_parts(ctypes.byref(self.desc), self.precision, wp, bp, ptr(self.buffer), int(parts), stream()),
+              "dn_mlp_pack_parts")
         self._keep = (ws, bs)  # keep sources alive until the pack kernel has run on this stream
 
 

@@ -59,7 +59,7 @@ class FusedNetFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:   # (inside forward the tensors themselves are detached views)
             raise RuntimeError("FusedNetFn differentiates w.r.t. the model parameters only; points / rays / view directions that "
                                "require grad must go through the nn.Linear composition (run_network does that by itself)")
-        pk = model.packed(log_xyz, log_dir)
+        pk = model.packed(log_xyz, log_dir, train=True)
         mods = model.linear_modules()
         key = model.param_key()
         if pk.key_bwd != key or torch.cuda.is_current_stream_capturing():
@@ -151,8 +151,8 @@ class RenderRaysTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model_c, model_f, rays, cfg, draws, thres, logs, *params):
         num_coarse, num_fine, lindisp, noise_std, white = cfg
-        pc = model_c.packed(*logs)
-        pf = model_f.packed(*logs) if model_f is not None else None
+        pc = model_c.packed(*logs, train=True)
+        pf = model_f.packed(*logs, train=True) if model_f is not None else None
         for model, pk in ((model_c, pc), (model_f, pf)):
             if model is None:
                 continue

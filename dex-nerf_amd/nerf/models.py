@@ -5,7 +5,7 @@ compatibility (out of the HIP scope)."""
 import torch
 from torch.optim.optimizer import register_optimizer_step_post_hook as _register_post_step
 
-from . import _ops
+from . import _hip, _ops
 
 _optimizer_steps = [0]   # bumped by a global optimizer post-step hook (see FlexibleNeRFModel.packed)
 
@@ -84,8 +84,10 @@ class FlexibleNeRFModel(torch.nn.Module):
                     include_input_dir=self.include_input_dir, use_viewdirs=self.use_viewdirs,
                     log_sampling_xyz=log_sampling_xyz, log_sampling_dir=log_sampling_dir)
 
-    def packed(self, log_sampling_xyz=True, log_sampling_dir=True):
-        """MFMA fragment stream for the current parameters (re-packed when any parameter changed).
+    def packed(self, log_sampling_xyz=True, log_sampling_dir=True, train=False):
+        """MFMA fragment stream for the current parameters (re-packed when any parameter changed).  `train=True` (the training
+        entry points: they never run the 48-point inference kernel) leaves that kernel's own stream stale; the next caller
+        without it - any render - brings it up to date.
 
         "Changed" = a new storage, a bumped tensor version (every ordinary in-place op), or ANY optimizer step since the
         last pack: fused optimizers (`Adam(fused=True)`) update parameters without bumping their versions."""
@@ -100,9 +102,18 @@ class FlexibleNeRFModel(torch.nn.Module):
             self._packed[slot] = pk
         # under stream capture always (re)pack: a captured graph must contain the pack of the weights it runs on, whatever
         # the host-side cache believes at capture time
-        if pk.key != key or (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
-            pk.pack([m.weight for m in mods], [m.bias for m in mods])
-            pk.key = key
+        capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        parts = 0
+        if pk.key != key or capturing:
+            parts |= _hip.PACK_CORE
+        if not train and (pk.key48 != key or capturing):
+            parts |= _hip.PACK_G48
+        if parts:
+            pk.pack([m.weight for m in mods], [m.bias for m in mods], parts)
+            if parts & _hip.PACK_CORE:
+                pk.key = key
+            if parts & _hip.PACK_G48:
+                pk.key48 = key
         return pk
 
     def fused_ok(self):

@@ -1536,3 +1536,44 @@ def test_training_from_an_llff_capture(dev, tmp_path):
     first, last = res["history"][0], res["history"][-1]
     assert np.isfinite(last[1]) and last[2] - first[2] > 6.0, (first, last)
     assert res["val_psnr"] > 12.0 and "dex_best_threshold" not in res
+
+
+def test_training_leaves_the_inference_stream_stale_and_a_render_refreshes_it(dev):
+    """dn_mlp_pack_parts: the training entry points re-pack only the core stream after an optimizer step (they never run the
+    48-point inference kernel); the first render afterwards must bring that kernel's own stream up to date - a bf16 render after
+    training steps equals the render of a fresh model holding the same parameters, bit for bit."""
+    import nerf
+    nerf.set_precision("bf16")
+    try:
+        torch.manual_seed(21)
+        mkw = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+        m = nerf.models.FlexibleNeRFModel(**mkw).to(dev)
+        ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+        n, s = 64, 48
+        pts = torch.randn(n, s, 3, device=dev)
+        vd = torch.nn.functional.normalize(torch.randn(n, 3, device=dev), dim=-1)
+        rays = torch.cat([torch.zeros(n, 8, device=dev), vd], -1)
+        with torch.no_grad():
+            before = nerf.run_network(m, pts, rays, 1 << 20, ex, ed)          # packs both streams
+        pk = m.packed()
+        assert pk.key48 == pk.key
+        opt = torch.optim.Adam(m.parameters(), lr=1e-2, fused=True)
+        for _ in range(2):
+            out = nerf.run_network(m, pts, rays, 1 << 20, ex, ed)             # training path: core stream only
+            opt.zero_grad(set_to_none=True)
+            (out ** 2).mean().backward()
+            opt.step()
+        out = nerf.run_network(m, pts, rays, 1 << 20, ex, ed)                 # (a training forward on the updated parameters)
+        pk = m.packed(train=True)
+        assert pk.key48 != pk.key                                             # the inference stream is two optimizer steps old
+        with torch.no_grad():
+            after = nerf.run_network(m, pts, rays, 1 << 20, ex, ed)           # render: refreshes it
+        assert m.packed().key48 == m.packed().key
+        fresh = nerf.models.FlexibleNeRFModel(**mkw).to(dev)
+        fresh.load_state_dict(m.state_dict())
+        with torch.no_grad():
+            ref = nerf.run_network(fresh, pts, rays, 1 << 20, ex, ed)
+        assert torch.equal(after, ref)
+        assert not torch.equal(after, before)
+    finally:
+        nerf.set_precision("fp32")

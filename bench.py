@@ -37,42 +37,51 @@ M_THRES = [float(m) for m in range(5, 105, 5)]
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 
 
-def build_scene(dev, rank):
+def build_scene(dev, rank, h=H, w=W, nc=NC, nf=NF, model_kw=None, near=2.0, far=6.0):
     import nerf
     from nerf import synthetic as syn
+    model_kw = MODEL_KW if model_kw is None else model_kw
     models = []
     for seed, bias in ((42, -150.0), (43, -20.0)):
-        m = nerf.models.FlexibleNeRFModel(**MODEL_KW)
-        m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(seed, sigma_bias=bias, **MODEL_KW).items()})
+        m = nerf.models.FlexibleNeRFModel(**model_kw)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(seed, sigma_bias=bias, **model_kw).items()})
         models.append(m.to(dev))
-    mode = dict(chunksize=H * W, lindisp=False, num_coarse=NC, num_fine=NF, perturb=False,
+    mode = dict(chunksize=h * w, lindisp=False, num_coarse=nc, num_fine=nf, perturb=False,
                 radiance_field_noise_std=0.0, white_background=False)
-    cfg = nerf.CfgNode(dict(dataset=dict(near=2.0, far=6.0, no_ndc=True),
+    cfg = nerf.CfgNode(dict(dataset=dict(near=near, far=far, no_ndc=True),
                             nerf=dict(use_viewdirs=True, train=dict(mode), validation=dict(mode))))
-    k_mat = torch.from_numpy(syn.intrinsic(H, W)).to(dev)
+    k_mat = torch.from_numpy(syn.intrinsic(h, w)).to(dev)
     e_mat = torch.from_numpy(syn.scene_pose(7 + rank)).to(dev)   # each rank: its own view of the scene
-    ro, rd = nerf.get_ray_bundle(H, W, float(k_mat[0, 0]), e_mat, k_mat)
+    ro, rd = nerf.get_ray_bundle(h, w, float(k_mat[0, 0]), e_mat, k_mat)
     ex, ed = nerf.get_embedding_function(10, True, True), nerf.get_embedding_function(4, True, True)
     return models, cfg, ro, rd, ex, ed
 
 
 def render(models, cfg, ro, rd, ex, ed):
     import nerf
+    h, w = ro.shape[0], ro.shape[1]
     with torch.no_grad():
-        return nerf.run_one_iter_of_nerf(H, W, 1.0, models[0], models[1], ro, rd, cfg, mode="validation",
+        return nerf.run_one_iter_of_nerf(h, w, 1.0, models[0], models[1], ro, rd, cfg, mode="validation",
                                          encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=M_THRES)
 
 
-def time_dominant_kernel(models, ro, rd, precision, reps=5):
-    """HIP-event timing of the dominant kernel (fused PE+MLP on the fine network, 160,000 x 192 points) on the
-    stream it is launched on (PyTorch's current stream)."""
+def render_dtype():
+    """Arithmetic type of the no-grad render under the current precision + render policy (nerf.set_render_policy)."""
+    from nerf import _hip, _ops
+    return {_hip.PREC_F32: "fp32", _hip.PREC_BF16: "bf16", _hip.PREC_F16: "fp16"}[_ops.render_precision()]
+
+
+def time_dominant_kernel(models, ro, rd, precision=None, reps=5, samples=NC + NF, flop_per_point=FLOP_PER_POINT, near=2.0, far=6.0):
+    """HIP-event timing of the dominant kernel (fused PE+MLP on the fine network, all rays x all samples of the image) on the
+    stream it is launched on (PyTorch's current stream), in the precision the no-grad render runs in."""
     from nerf import _ops
     dev = ro.device
-    rays = torch.cat([ro.reshape(-1, 3), rd.reshape(-1, 3), torch.full((H * W, 1), 2.0, device=dev),
-                      torch.full((H * W, 1), 6.0, device=dev),
+    n = ro.shape[0] * ro.shape[1]
+    rays = torch.cat([ro.reshape(-1, 3), rd.reshape(-1, 3), torch.full((n, 1), near, device=dev),
+                      torch.full((n, 1), far, device=dev),
                       torch.nn.functional.normalize(rd.reshape(-1, 3), dim=-1)], -1).contiguous()
-    z = torch.sort(torch.rand(H * W, NC + NF, device=dev) * 4.0 + 2.0, -1)[0].contiguous()
-    packed = models[1].packed()
+    z = torch.sort(torch.rand(n, samples, device=dev) * (far - near) + near, -1)[0].contiguous()
+    packed = models[1].packed(precision=_ops.render_precision())
     _ops.run_network_rays(packed, rays, z)
     torch.cuda.synchronize()
     times = []
@@ -84,23 +93,47 @@ def time_dominant_kernel(models, ro, rd, precision, reps=5):
         b.synchronize()
         times.append(a.elapsed_time(b) * 1e-3)
     t = float(np.mean(times))
-    flops = H * W * (NC + NF) * FLOP_PER_POINT
+    flops = n * samples * flop_per_point
     return t, flops / t / 1e12
 
 
+def other_config_render(dev, rank, tag, h, w, nc, nf, model_kw, flop_per_point, near, far, steps=3):
+    """BASELINE configs[2] / configs[3] as single-GPU render workloads, with the fine-net launch's roofline (informational legs of
+    the line: the headline stays configs[1])."""
+    models, cfg, ro, rd, ex, ed = build_scene(dev, rank, h, w, nc, nf, model_kw, near, far)
+    render(models, cfg, ro, rd, ex, ed)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        render(models, cfg, ro, rd, ex, ed)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kt, ktf = time_dominant_kernel(models, ro, rd, reps=3, samples=nc + nf, flop_per_point=flop_per_point, near=near, far=far)
+    peak = PEAK_TFLOPS[render_dtype()]
+    pts = nc + (nc + nf)
+    return {"workload": tag, "value": h * w / dt, "unit": "rays/s", "ms_per_image": dt * 1e3, "dtype": render_dtype(),
+            "kernel_ms": kt * 1e3, "tflops": ktf, "peak": peak, "frac": ktf / peak,
+            "whole_path_tflops": h * w / dt * pts * flop_per_point / 1e12, "flop_per_ray": pts * flop_per_point}
+
+
 def geometry48(precision):
-    """True when the bf16 fine-net launch runs the 48-points-per-wave kernel (the default; DEXNERF_BF16_GEOM=32 keeps the 32-point one)."""
-    return precision == "bf16" and os.environ.get("DEXNERF_BF16_GEOM", "") != "32"
+    """True when the 16-bit fine-net launch runs the 48-points-per-wave kernel (the default; DEXNERF_BF16_GEOM=32 keeps the 32-point one)."""
+    return precision in ("bf16", "fp16") and os.environ.get("DEXNERF_BF16_GEOM", "") != "32"
 
 
 def pmc_record(precision):
-    """The committed rocprofv3 --pmc passes on this exact launch (scripts/pmc_fine_net.sh -> profiles/r02_pmc_fine_net.json:
+    """The committed rocprofv3 --pmc passes on this exact launch (scripts/pmc_fine_net.sh -> profiles/r0N_pmc_fine_net*.json:
     FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes, FETCH_SIZE doubled per the gfx950 correction of
-    MI355X_MICROARCH.md).  bench.py itself cannot run the profiler; the record is for the 48-point bf16 kernel."""
-    path = os.path.join(REPO, "profiles", "r02_pmc_fine_net.json")
-    if not geometry48(precision) or not os.path.exists(path):
+    MI355X_MICROARCH.md).  bench.py itself cannot run the profiler; the records are for the 48-point kernel, per input type."""
+    if not geometry48(precision):
         return {}
-    return json.load(open(path)).get("derived", {})
+    for name in (f"r03_pmc_fine_net_{precision}.json", "r02_pmc_fine_net.json" if precision == "bf16" else ""):
+        path = os.path.join(REPO, "profiles", name)
+        if name and os.path.exists(path):
+            rec = json.load(open(path)).get("derived", {})
+            rec["record"] = "profiles/" + name
+            return rec
+    return {}
 
 
 def library_gemm_tflops(dev, precision):
@@ -307,24 +340,31 @@ def main():
         note(f"data-parallel training step: {train_dp['ms_per_step']:.2f} ms, all-reduce alone {train_dp['allreduce_ms']:.3f} ms")
     result = None
     if rank == 0:
-        kt, ktf = time_dominant_kernel(models, ro, rd, args.precision)
-        note(f"dominant kernel {kt * 1e3:.2f} ms = {ktf:.0f} TFLOP/s")
-        peak = PEAK_TFLOPS[args.precision]
+        rdt = render_dtype()   # 'bf16' runs its no-grad renders in fp16 under the default render policy (nerf.set_render_policy)
+        kt, ktf = time_dominant_kernel(models, ro, rd)
+        note(f"dominant kernel ({rdt}) {kt * 1e3:.2f} ms = {ktf:.0f} TFLOP/s")
+        peak = PEAK_TFLOPS[rdt]
         whole_tf = value / world * POINTS_PER_RAY * FLOP_PER_POINT / 1e12
         result = {
             "metric": "rays/sec (64+128 samples) + PSNR vs ref, 400x400 scene", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": rdt,
             "data": "synthetic",
+            "precision_policy": {"set_precision": args.precision, "render": rdt, "train": args.precision,
+                                 "what": "nerf.set_precision('bf16'): training kernels in bf16; no-grad renders (what this metric times, and "
+                                         "what the Dex depth sweep of train_dexnerf_rgb.py:391-408 reads) run the fp16 instance of the same "
+                                         "MFMA kernel, guarded by the non-finite count of the compositing passes (falls back to bf16); "
+                                         "DEXNERF_BF16_RENDER=bf16 / nerf.set_render_policy('bf16') renders in bf16 - leg `bf16_render_mode`"},
             "config": {"workload": "C2 render: 400x400 rays/step/GPU, 64 coarse + 128 fine samples, coarse+fine "
                                    "FlexibleNeRFModel D8/W256/skip4 + viewdirs, PE L=10/4, 20 Dex thresholds, "
                                    "validation mode (det. resampling, no noise)",
                        "rays_per_step_per_gpu": H * W, "sharding": f"{world} ranks x own view (no collective in the path)"},
             "roofline": {"bound": "mfma", "achieved": ktf, "peak": peak, "unit": "TFLOP/s", "frac": ktf / peak,
-                         "traffic": pmc_record(args.precision).get("hbm_bytes_per_launch"),
+                         "traffic": pmc_record(rdt).get("hbm_bytes_per_launch"),
+                         "traffic_record": pmc_record(rdt).get("record"),
                          "algorithmic_bytes": H * W * (NC + NF) * 20 + H * W * 44,
-                         "matrix_pipe_busy_frac_pmc": pmc_record(args.precision).get("matrix_pipe_busy_frac"),
-                         "kernel": ("mlp_forward48_kernel<256,1>" if geometry48(args.precision) else "mlp_forward_kernel<256,10,4>") + " (fine net, 160000x192 points)",
+                         "matrix_pipe_busy_frac_pmc": pmc_record(rdt).get("matrix_pipe_busy_frac"),
+                         "kernel": (f"mlp_forward48_kernel<256,{2 if rdt == 'fp16' else 1},8,16,1>" if geometry48(rdt) else "mlp_forward_kernel<256,10,4>") + " (fine net, 160000x192 points)",
                          "kernel_ms": kt * 1e3, "whole_path_tflops": whole_tf},
         }
         if train_dp is not None:
@@ -339,22 +379,26 @@ def main():
             result["psnr_vs_oracle_db"] = float(-10.0 * np.log10(max(mse, 1e-12)))
             result["dex_vs_oracle"] = dex_agreement(out, ref, sel, dev)
             result["gpu_over_cpu"] = value / world / cb["value"]
-        if args.precision == "bf16" and not args.no_cpu_baseline:
-            # the same render in the fp16 MFMA mode (same matrix rate, 10-bit mantissa): informational
-            nerf.set_precision("fp16")
-            render(models, cfg, ro, rd, ex, ed)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                out16 = render(models, cfg, ro, rd, ex, ed)
-            torch.cuda.synchronize()
-            dt16 = (time.perf_counter() - t1) / 3
-            rgb16 = out16[3].reshape(-1, 3)[torch.from_numpy(sel).to(dev)].cpu().numpy()
-            mse16 = float(np.mean((rgb16 - ref[3].numpy()) ** 2))
-            result["fp16_mode"] = {"value": H * W / dt16, "unit": "rays/s",
-                                   "psnr_vs_oracle_db": float(-10.0 * np.log10(max(mse16, 1e-12))),
-                                   "dex_vs_oracle": dex_agreement(out16, ref, sel, dev)}
-            nerf.set_precision(args.precision)
+        if args.precision == "bf16" and rdt == "fp16" and not args.no_cpu_baseline:
+            # the same render with the policy off: every kernel in bf16 (what rounds 1-2 reported as the headline)
+            nerf.set_render_policy("bf16")
+            try:
+                render(models, cfg, ro, rd, ex, ed)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    out16 = render(models, cfg, ro, rd, ex, ed)
+                torch.cuda.synchronize()
+                dt16 = (time.perf_counter() - t1) / 3
+                kt16, ktf16 = time_dominant_kernel(models, ro, rd, reps=3)
+                rgb16 = out16[3].reshape(-1, 3)[torch.from_numpy(sel).to(dev)].cpu().numpy()
+                mse16 = float(np.mean((rgb16 - ref[3].numpy()) ** 2))
+                result["bf16_render_mode"] = {"value": H * W / dt16, "unit": "rays/s", "kernel_ms": kt16 * 1e3, "tflops": ktf16,
+                                              "frac": ktf16 / PEAK_TFLOPS["bf16"],
+                                              "psnr_vs_oracle_db": float(-10.0 * np.log10(max(mse16, 1e-12))),
+                                              "dex_vs_oracle": dex_agreement(out16, ref, sel, dev)}
+            finally:
+                nerf.set_render_policy(None)
         if args.precision == "bf16" and not args.no_cpu_baseline:
             # the same render in the exact-fp32 parity mode (north_star's 1e-4 tolerance holds in this mode only): 3 steps
             nerf.set_precision("fp32")
@@ -379,6 +423,17 @@ def main():
                                        "dex_vs_oracle": dex_agreement(out32, ref, sel, dev)}
             finally:
                 nerf.set_precision(args.precision)
+        if world == 1 and not args.no_cpu_baseline:
+            # BASELINE configs[2] (Dex-NeRF transparent-object scene on the as-shipped 4 x 128 nets: 270x480 after the fork's half-res
+            # rule, 64+64, near 0.3 / far 4 - config/messytable-obj-remote.yml) and configs[3] as a single-GPU render (800x800, 64+192,
+            # D8/W256), 3 images each, with the fine-net launch's own roofline
+            kw_shipped = dict(MODEL_KW, num_layers=4, hidden_size=128)
+            result["c3_render"] = other_config_render(dev, rank, "C3 render: 270x480, 64+64 samples, 4x128 nets (as shipped), near 0.3 far 4",
+                                                      270, 480, 64, 64, kw_shipped, 167680, 0.3, 4.0)
+            result["c4_render"] = other_config_render(dev, rank, "C4 render: 800x800, 64+192 samples, D8/W256 nets",
+                                                      800, 800, 64, 192, MODEL_KW, FLOP_PER_POINT, 2.0, 6.0)
+            note(f"C3 {result['c3_render']['value'] / 1e6:.2f} M rays/s ({result['c3_render']['frac']:.3f} of peak), "
+                 f"C4 {result['c4_render']['value'] / 1e6:.2f} M rays/s ({result['c4_render']['frac']:.3f})")
         if not args.no_train and world == 1:
             result["train"] = train_rate(models, cfg, ro, rd, ex, ed)
         if not args.no_train and world == 1 and args.precision == "bf16":
@@ -410,7 +465,7 @@ def main():
                 result["train_as_shipped"] = {"error": f"{type(exc).__name__}: {exc}"}
             finally:
                 nerf.set_precision(args.precision)
-        result["roofline"]["library_gemm"] = library_gemm_tflops(dev, args.precision)
+        result["roofline"]["library_gemm"] = library_gemm_tflops(dev, rdt)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -46,6 +46,7 @@ static size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255);
 
 struct Workspace {
   float *z_c, *rf_c, *w_c, *z_f, *rf_f, *g_rf;
+  unsigned* status;   // the last 256 bytes: word 0 = non-finite raw radiance-field values met by this call's compositing
   size_t bytes;
 };
 
@@ -65,6 +66,7 @@ static Workspace carve(void* base, int64_t n, int nc, int nf, bool train = false
     w.rf_f = take(static_cast<size_t>(n) * (nc + nf) * 4);
   }
   if (train) w.g_rf = take(static_cast<size_t>(n) * (nc + nf) * 4);   // d loss / d raw radiance field, one network at a time
+  w.status = reinterpret_cast<unsigned*>(take(64));
   w.bytes = off;
   return w;
 }
@@ -96,23 +98,27 @@ extern "C" int dn_render_rays(const dn_mlp_desc* desc_coarse, const void* packed
   if (n_rays == 0) return 0;
   Workspace w = carve(workspace, n_rays, num_coarse, num_fine);
   int rc;
+  {
+    hipError_t e = hipMemsetAsync(w.status, 0, 256, as_stream(stream));
+    if (e != hipSuccess) { set_error("dn_render_rays: hipMemsetAsync: %s", hipGetErrorString(e)); return -static_cast<int>(e); }
+  }
   if ((rc = dn_coarse_depths(rays, ray_stride, n_rays, num_coarse, lindisp, t_rand, w.z_c, stream))) return rc;
   if ((rc = dn_run_network(desc_coarse, precision, packed_coarse, nullptr, nullptr, rays, ray_stride, w.z_c, n_rays,
                            num_coarse, w.rf_c, stream)))
     return rc;
   const bool fine = num_fine > 0;
   // Dex depths come from the fine pass (train_utils.py:199-201); coarse-only renders report the coarse ones.
-  if ((rc = dn_volume_render(w.rf_c, w.z_c, rays + 3, ray_stride, noise_c, noise_std, white_background, h_m_thres,
-                             fine ? 0 : n_thres, n_rays, num_coarse, rgb_c, nullptr, acc_c, w.w_c, depth_c,
-                             fine ? nullptr : dex_f, stream)))
+  if ((rc = volume_render_counting(w.rf_c, w.z_c, rays + 3, ray_stride, noise_c, noise_std, white_background, h_m_thres,
+                                   fine ? 0 : n_thres, n_rays, num_coarse, rgb_c, nullptr, acc_c, w.w_c, depth_c,
+                                   fine ? nullptr : dex_f, w.status, stream)))
     return rc;
   if (!fine) return 0;
   if ((rc = dn_fine_depths(w.z_c, w.w_c, u, n_rays, num_coarse, num_fine, w.z_f, nullptr, stream))) return rc;
   if ((rc = dn_run_network(desc_fine, precision, packed_fine, nullptr, nullptr, rays, ray_stride, w.z_f, n_rays,
                            num_coarse + num_fine, w.rf_f, stream)))
     return rc;
-  return dn_volume_render(w.rf_f, w.z_f, rays + 3, ray_stride, noise_f, noise_std, white_background, h_m_thres, n_thres,
-                          n_rays, num_coarse + num_fine, rgb_f, nullptr, acc_f, nullptr, depth_f, dex_f, stream);
+  return volume_render_counting(w.rf_f, w.z_f, rays + 3, ray_stride, noise_f, noise_std, white_background, h_m_thres, n_thres,
+                                n_rays, num_coarse + num_fine, rgb_f, nullptr, acc_f, nullptr, depth_f, dex_f, w.status, stream);
 }
 
 // ---- predict_and_render_radiance under autograd (reference nerf/train_utils.py:92-202 + loss.backward(),

@@ -39,10 +39,11 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float4* __restrict__ rf, const float* __restrict__ z, const float* __restrict__ rd, int rd_stride,
     const float* __restrict__ noise, float noise_std, int white, ThresArgs th, int n_thres, int64_t n_rays, int S,
     float* __restrict__ rgb, float* __restrict__ disp, float* __restrict__ acc, float* __restrict__ weights,
-    float* __restrict__ depth, float* __restrict__ dex) {
+    float* __restrict__ depth, float* __restrict__ dex, unsigned* __restrict__ nonfinite) {
   const int lane = lane_id();
   const int64_t ray = static_cast<int64_t>(blockIdx.x) * kRaysPerBlock + (threadIdx.x >> 6);
   if (ray >= n_rays) return;  // wave-uniform exit; no block-level sync in this kernel
+  unsigned n_bad = 0;   // non-finite raw values of this lane's samples (counted only when the caller asks: fp16 overflow guard)
   const float dx = rd[ray * rd_stride + 0], dy = rd[ray * rd_stride + 1], dz = rd[ray * rd_stride + 2];
   const float rd_norm = sqrtf((dx * dx + dy * dy) + dz * dz);
   const float* zr = z + ray * S;
@@ -56,6 +57,11 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const bool valid = s < S;
     const int sc = valid ? s : S - 1;
     const float4 raw = rfr[sc];
+    if (nonfinite != nullptr && valid) {
+      // x - x is 0 for every finite x and NaN for +-inf / NaN
+      const float probe = ((raw.x - raw.x) + (raw.y - raw.y)) + ((raw.z - raw.z) + (raw.w - raw.w));
+      n_bad += (probe != 0.0f) ? 1u : 0u;
+    }
     const float z0 = zr[sc];
     const float z1 = (sc + 1 < S) ? zr[sc + 1] : z0;
     const float nz = (noise != nullptr && noise_std > 0.0f) ? noise[ray * S + sc] : 0.0f;
@@ -95,6 +101,10 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     }
   }
   s_r = wave_sum(s_r); s_g = wave_sum(s_g); s_b = wave_sum(s_b); s_d = wave_sum(s_d); s_a = wave_sum(s_a);
+  if (nonfinite != nullptr && __ballot(n_bad != 0u) != 0ull) {   // (wave-uniform branch; never taken on healthy weights)
+    const unsigned total = static_cast<unsigned>(wave_sum(static_cast<float>(n_bad)));
+    if (lane == 0) atomicAdd(nonfinite, total);
+  }
   if (lane == 0) {
     if (white) {
       const float bg = 1.0f - s_a;
@@ -218,6 +228,15 @@ extern "C" int dn_volume_render(const float* rf, const float* z, const float* rd
                                 float noise_std, int white_background, const float* h_m_thres, int n_thres,
                                 int64_t n_rays, int n_samples, float* rgb, float* disp, float* acc, float* weights,
                                 float* depth, float* dex, dn_stream_t stream) {
+  return dn::volume_render_counting(rf, z, rd, rd_stride, noise, noise_std, white_background, h_m_thres, n_thres, n_rays, n_samples,
+                                    rgb, disp, acc, weights, depth, dex, nullptr, stream);
+}
+
+// dn_volume_render + a count of the non-finite raw radiance-field values it met, added to *nonfinite (device word, may be NULL)
+int dn::volume_render_counting(const float* rf, const float* z, const float* rd, int rd_stride, const float* noise,
+                               float noise_std, int white_background, const float* h_m_thres, int n_thres,
+                               int64_t n_rays, int n_samples, float* rgb, float* disp, float* acc, float* weights,
+                               float* depth, float* dex, unsigned* nonfinite, dn_stream_t stream) {
   if (n_rays == 0) return 0;
   DN_REQUIRE(rf && z && rd && n_rays >= 0 && n_samples >= 1 && rd_stride >= 3, "dn_volume_render: bad arguments");
   DN_REQUIRE(n_thres >= 0 && n_thres <= kMaxThres, "dn_volume_render: at most %d Dex thresholds", kMaxThres);
@@ -229,7 +248,7 @@ extern "C" int dn_volume_render(const float* rf, const float* z, const float* rd
   const unsigned grid = static_cast<unsigned>((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
   hipLaunchKernelGGL(composite_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float4*>(rf), z, rd, rd_stride, noise, noise_std, white_background, th,
-                     n_thres, n_rays, n_samples, rgb, disp, acc, weights, depth, dex);
+                     n_thres, n_rays, n_samples, rgb, disp, acc, weights, depth, dex, nonfinite);
   return check_launch("dn_volume_render");
 }
 

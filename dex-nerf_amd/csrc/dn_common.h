@@ -32,6 +32,13 @@ inline int check_launch(const char* what) {
 int ensure_big_lds(const void* kernel);   // 0 or -(hipError_t), error string set
 int device_cus();
 
+// composite.hip: dn_volume_render that also counts the non-finite raw radiance-field values it reads into *nonfinite
+// (device word, NULL = do not count) - the fp16 render guard of dn_render_rays
+int volume_render_counting(const float* rf, const float* z, const float* rd, int rd_stride, const float* noise, float noise_std,
+                           int white_background, const float* h_m_thres, int n_thres, int64_t n_rays, int n_samples, float* rgb,
+                           float* disp, float* acc, float* weights, float* depth, float* dex, unsigned* nonfinite,
+                           dn_stream_t stream);
+
 #define DN_REQUIRE(cond, ...)     \
   do {                            \
     if (!(cond)) {                \

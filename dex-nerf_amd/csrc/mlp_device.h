@@ -14,8 +14,11 @@
     (defined(DN_EXP_NODMA) || defined(DN_EXP_NOREAD) || defined(DN_EXP_SHALLOW) || defined(DN_EXP_LOOSEWAIT) ||    \
      defined(DN_EXP_NOBARRIER) || defined(DN_EXP_REGSTAGE) || defined(DN_EXP_ROTATE) || defined(DN_EXP_SETPRIO) || \
      defined(DN_EXP_NOPIN) || defined(DN_EXP_NOSAVE) || defined(DN_EXP_NOSETTLE) || defined(DN_STAMP) || defined(DN_STORE_POLICY_ID) || \
-     defined(DN_WG_NOREAD) || defined(DN_WG_NOSTAGE) || defined(DN_WG_STAMP) || defined(DN_WG_EPI) || defined(DN_WG_LOAD_POLICY_ID))
-#error "DN_EXP_* / DN_WG_* / DN_STORE_POLICY_ID are ablation hooks: build them with scripts/build_exp.sh (-DDN_ABLATION_BUILD), never into libdexnerf_hip.so"
+     defined(DN_WG_NOREAD) || defined(DN_WG_NOSTAGE) || defined(DN_WG_STAMP) || defined(DN_WG_EPI) || defined(DN_WG_LOAD_POLICY_ID) ||  \
+     defined(DN_WG_ONLY) || defined(DN_G48_PREFETCH) || defined(DN_G48_COMPILER_READS) || defined(DN_G48_SYMMETRIC_DMA) ||               \
+     defined(DN_G48_PRIO) || defined(DN_G48_BARRIER_EVERY_PHASE) || defined(DN_G48_SKIP_PE_FROM_LDS) ||                                 \
+     (defined(DN_PREFETCH) && !defined(DN_PREFETCH_SET_BY_KERNEL_SOURCE)))
+#error "DN_EXP_* / DN_WG_* / DN_G48_* / DN_PREFETCH / DN_STORE_POLICY_ID are ablation hooks: build them with scripts/build_exp.sh (-DDN_ABLATION_BUILD), never into libdexnerf_hip.so"
 #endif
 
 namespace dn {
@@ -656,15 +659,19 @@ __device__ __forceinline__ void store16_uniform(const char* base, unsigned lane1
 }
 
 // ---- 8-bit saved tensors (DN_PREC_BF16_S8): a bf16 B piece (8 values per lane) -> 8 bytes --------------------------
-// GRAD = false: e4m3 (activations, post-ReLU, O(1)); GRAD = true: e5m2 of value * scale, saturated (e5m2 has infinities).
+// GRAD = false: e4m3 (activations, O(1)), saturated at +-448 (OCP e4m3 has no infinity: an unclamped overflow converts to NaN,
+// and one NaN activation poisons a whole layer's weight gradient); GRAD = true: e5m2 of value * scale, saturated at +-57344
+// (e5m2 has infinities).  One v_med3_f32 per element either way.
 // From the bf16 values the kernel itself used (exact in fp32), so the stored bytes equal convert_s8_kernel's on the bf16 buffers.
+constexpr float kE4m3Max = 448.0f, kE5m2Max = 57344.0f;
 template <bool GRAD>
 __device__ __forceinline__ void piece_to_8bit(const bf16x8& v, float scale, unsigned& w0, unsigned& w1) {
   float f[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     f[e] = static_cast<float>(v[e]);
-    if constexpr (GRAD) f[e] = fminf(fmaxf(f[e] * scale, -57344.0f), 57344.0f);
+    if constexpr (GRAD) f[e] = __builtin_amdgcn_fmed3f(f[e] * scale, -kE5m2Max, kE5m2Max);
+    else f[e] = __builtin_amdgcn_fmed3f(f[e], -kE4m3Max, kE4m3Max);
   }
   int a = 0, b = 0;
   if constexpr (GRAD) {

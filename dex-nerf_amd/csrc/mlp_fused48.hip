@@ -7,10 +7,15 @@
 // Every A fragment read from LDS feeds three MFMAs: 384 points per pass of the weight stream instead of 256.
 // A-fragment FIFO of 2 pieces here (4 in the 32-point kernels): a piece lasts three MFMAs = 48 cycles, and the 256-VGPR
 // budget of two waves per SIMD is spent on the two 96-register activation sets
-#ifndef DN_G48_PREFETCH
-#define DN_G48_PREFETCH 2
+#if defined(DN_PREFETCH) && !defined(DN_ABLATION_BUILD)
+#error "DN_PREFETCH is set by this file (the 48-point kernel's FIFO depth); a command-line value is an ablation hook (scripts/build_exp.sh)"
 #endif
+#ifdef DN_G48_PREFETCH   // (ablation hook, refused by mlp_device.h outside an ablation build)
 #define DN_PREFETCH DN_G48_PREFETCH
+#else
+#define DN_PREFETCH 2
+#endif
+#define DN_PREFETCH_SET_BY_KERNEL_SOURCE 1
 #define DN_PIPE_SCALAR_STATE 1   // ring bookkeeping in SGPRs: frees the VGPRs that were spilling (0.5 % on the launch)
 #ifndef DN_G48_COMPILER_READS    // (ablation hook: the r01 pipeline with compiler-issued reads and waits)
 #define DN_PIPE_ASM_READS 1      // A-fragment / bias LDS reads and their counted waits as opaque asm (mlp_device.h Pipe)

@@ -1395,7 +1395,8 @@ __global__ void convert_s8_kernel(const char* __restrict__ native, long long n_t
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         v[e] = static_cast<float>(src[e]) * scale;
-        if constexpr (WHICH == 1) v[e] = fminf(fmaxf(v[e], -57344.0f), 57344.0f);   // e5m2 has infinities: saturate instead
+        // saturate: e5m2 has infinities, e4m3 turns an overflow into NaN (same clamps as piece_to_8bit: the bytes must agree)
+        v[e] = __builtin_amdgcn_fmed3f(v[e], WHICH == 1 ? -kE5m2Max : -kE4m3Max, WHICH == 1 ? kE5m2Max : kE4m3Max);
       }
 #pragma unroll
       for (int d = 0; d < 2; ++d) {

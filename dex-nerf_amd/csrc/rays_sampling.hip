@@ -5,6 +5,17 @@
 
 namespace dn {
 
+// Cross-lane hand-off through the wave's OWN LDS rows (one lane writes, another reads): a wave's DS instructions execute in
+// order, so no s_barrier is needed - but the compiler must not move the reads above the neighbouring lanes' writes.  The bare
+// wave_barrier intrinsic does not order memory for alias analysis; the wavefront-scope fence does (it emits no instruction
+// beyond, at most, an s_waitcnt lgkmcnt).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // S1 get_ray_bundle (reference nerf/nerf_helpers.py:67-112)
 // ------------------------------------------------------------------------------------------------
@@ -321,9 +332,9 @@ __global__ __launch_bounds__(256) void sampler_kernel(const float* __restrict__ 
     for (int i = lane; i < L; i += 64) w[i] = weights[ray * nc + 1 + i] + 1e-5f;
     for (int i = lane; i < nc; i += 64) sbuf[i] = zc[i];
   }
-  __builtin_amdgcn_wave_barrier();   // (this wave's own rows: DS instructions of a wave execute in order)
+  wave_lds_sync();   // (this wave's own rows: DS instructions of a wave execute in order)
   build_cdf(w, cdf, B);
-  __builtin_amdgcn_wave_barrier();
+  wave_lds_sync();
   for (int q = lane; q < nf; q += 64) {
     const float uq = (u != nullptr) ? u[ray * nf + q] : linspace_elem(0.0f, 1.0f, nf, q);
     int ind;
@@ -339,7 +350,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(const float* __restrict__ 
     const int total = nc + nf;
     // Everything below touches this wave's own LDS rows only: a wave's DS instructions execute in order, so no workgroup
     // barrier is needed between the steps (the round-1 kernel had one per bitonic stage: 36 for 192 depths).
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     // sort(cat(z_coarse, z_samples)) (train_utils.py:173).  Both halves are usually already ascending - the coarse depths
     // always, the samples whenever u is ascending (deterministic resampling: every validation render) - and then the sort is
     // a MERGE: an element's output slot = its own index + the number of elements of the other half in front of it (coarse
@@ -374,12 +385,12 @@ __global__ __launch_bounds__(256) void sampler_kernel(const float* __restrict__ 
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (sbuf[mid] <= v) lo = mid + 1; else hi = mid; }
         vf[e] = v; sf[e] = q + lo;
       }
-      __builtin_amdgcn_wave_barrier();   // every search has read its operands (one wave, in order): now overwrite in place
+      wave_lds_sync();   // every search has read its operands (one wave, in order): now overwrite in place
 #pragma unroll
       for (int e = 0; e < kMergeCoarse; ++e) if (lane + 64 * e < nc) sbuf[sc[e]] = vc[e];
 #pragma unroll
       for (int e = 0; e < kMergeFine; ++e) if (lane + 64 * e < nf) sbuf[sf[e]] = vf[e];
-      __builtin_amdgcn_wave_barrier();
+      wave_lds_sync();
       if (live)
         for (int i = lane; i < total; i += 64) z_fine[ray * total + i] = sbuf[i];
       return;
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(const float* __restrict__ 
     // bitonic sort of sort_len (power of two) floats by one wave
     for (int k = 2; k <= sort_len; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         for (int t = lane; t < (sort_len >> 1); t += 64) {
           const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
           const int hi = lo | j;
@@ -401,7 +412,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(const float* __restrict__ 
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     if (live)
       for (int i = lane; i < total; i += 64) z_fine[ray * total + i] = sbuf[i];
   }

@@ -28,6 +28,35 @@ def set_precision(name):
                   "f16": _hip.PREC_F16, "bf16-s8": _hip.PREC_BF16, "bf16_s8": _hip.PREC_BF16}[name]
 
 
+_render16 = [None]   # what no-grad renders run in the bf16 modes: None = the environment decides (default "fp16")
+
+
+def set_render_policy(name):
+    """What `predict_and_render_radiance` WITHOUT autograd (validation images, the Dex depth sweep, eval_nerf) runs while the
+    precision is 'bf16' / 'bf16-s8': "fp16" (default) = the fp16 instance of the same kernel - same matrix rate and layouts, a
+    10-bit mantissa: ~58 dB / 0.997 Dex-depth agreement against fp32 where bf16 gives ~42 dB / 0.976, because the Dex readout
+    is an argmax over thresholded sigma - guarded against fp16's range (65504): a render whose raw radiance field holds a
+    non-finite value is repeated in bf16, with one warning; "bf16" = renders in bf16 like the training kernels.  The
+    environment variable DEXNERF_BF16_RENDER sets the default.  Training is never affected."""
+    name = None if name is None else str(name).lower()
+    if name not in (None, "fp16", "bf16"):
+        raise ValueError("render policy: 'fp16', 'bf16' or None (environment default)")
+    _render16[0] = name
+
+
+def get_render_policy():
+    import os
+    name = _render16[0] or os.environ.get("DEXNERF_BF16_RENDER", "fp16").lower()
+    return name if name in ("fp16", "bf16") else "fp16"
+
+
+def render_precision():
+    """Precision code of no-grad renders under the current precision + render policy."""
+    if _precision == _hip.PREC_BF16 and get_render_policy() == "fp16":
+        return _hip.PREC_F16
+    return _precision
+
+
 def get_precision():
     if _save8 and _precision == _hip.PREC_BF16:
         return "bf16-s8"
@@ -173,6 +202,15 @@ class PackedMLP:
               "dn_mlp_pack_parts")
         self._keep = (ws, bs)  # keep sources alive until the pack kernel has run on this stream
 
+    def require_fresh_inference_stream(self, what):
+        """The inference entry points may run the 48-point kernel, whose stream lives behind the core one in `buffer` and is
+        left stale by the training entry points (FlexibleNeRFModel.packed(train=True)).  A caller that kept this object across
+        optimizer steps instead of asking `model.packed()` again would render OLD weights without any error: refuse."""
+        if self.key48 != self.key:
+            raise RuntimeError(f"{what}: the packed network's 48-point inference stream is older than its core stream (it was "
+                               "last packed by a training entry point) - obtain the packed network with model.packed() "
+                               "(no train=True) before rendering")
+
 
 def pack_backward(packed, weights):
     """(Re)build the transposed weight stream used by dn_mlp_backward_data."""
@@ -289,6 +327,7 @@ def mlp_weight_grad_all_into(packed, act, grads, n_points, views, prec=None):
 
 
 def run_network_pts(packed, pts, viewdirs, samples_per_ray):
+    packed.require_fresh_inference_stream("run_network")
     pts = f32c(pts).reshape(-1, 3)
     n_pts = pts.shape[0]
     assert n_pts % samples_per_ray == 0
@@ -300,6 +339,7 @@ def run_network_pts(packed, pts, viewdirs, samples_per_ray):
 
 
 def run_network_rays(packed, rays, z_vals):
+    packed.require_fresh_inference_stream("run_network")
     rays, z_vals = f32c(rays), f32c(z_vals)
     n, s = z_vals.shape
     out = torch.empty((n, s, 4), dtype=torch.float32, device=rays.device)
@@ -409,6 +449,9 @@ _ws_cache = {}
 
 def render_rays(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, noise_std, white, m_thres, draws=None):
     """dn_render_rays: the whole predict_and_render_radiance forward for one ray chunk (no autograd)."""
+    packed_c.require_fresh_inference_stream("render_rays")
+    if packed_f is not None:
+        packed_f.require_fresh_inference_stream("render_rays")
     rays = f32c(rays)
     n = rays.shape[0]
     dev = rays.device
@@ -422,6 +465,7 @@ def render_rays(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, noise_s
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         _ws_cache[key] = ws
+    ws = ws[:nbytes]   # (the status block is the last 256 bytes of what THIS call asked for)
 
     def new(*shape):
         return torch.empty(shape, dtype=torch.float32, device=dev)
@@ -437,7 +481,14 @@ def render_rays(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, noise_s
         host_floats(m_thres), k, ptr(t["t_rand"]), ptr(t["noise_c"]), ptr(t["u"]), ptr(t["noise_f"]),
         ptr(rgb_c), ptr(depth_c), ptr(acc_c), ptr(rgb_f), ptr(depth_f), ptr(acc_f), ptr(dex), ptr(ws), stream()),
         "dn_render_rays")
+    render_rays.last_workspace = ws
     return rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f, dex
+
+
+def render_nonfinite_count(ws=None):
+    """Status word of the last dn_render_rays call on this stream (synchronises): non-finite raw radiance-field samples."""
+    ws = render_rays.last_workspace if ws is None else ws
+    return int(ws[ws.numel() - 256: ws.numel() - 252].view(torch.int32).item())
 
 
 # ---- predict_and_render_radiance under autograd: one C call forward, one (or two halves) backward ----------------------

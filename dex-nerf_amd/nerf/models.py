@@ -84,7 +84,7 @@ class FlexibleNeRFModel(torch.nn.Module):
                     include_input_dir=self.include_input_dir, use_viewdirs=self.use_viewdirs,
                     log_sampling_xyz=log_sampling_xyz, log_sampling_dir=log_sampling_dir)
 
-    def packed(self, log_sampling_xyz=True, log_sampling_dir=True, train=False):
+    def packed(self, log_sampling_xyz=True, log_sampling_dir=True, train=False, precision=None):
         """MFMA fragment stream for the current parameters (re-packed when any parameter changed).  `train=True` (the training
         entry points: they never run the 48-point inference kernel) leaves that kernel's own stream stale; the next caller
         without it - any render - brings it up to date.
@@ -93,7 +93,7 @@ class FlexibleNeRFModel(torch.nn.Module):
         last pack: fused optimizers (`Adam(fused=True)`) update parameters without bumping their versions."""
         mods = self.linear_modules()
         dev = mods[0].weight.device
-        prec = _ops._precision
+        prec = _ops._precision if precision is None else precision   # (a render may ask for fp16 beside the bf16 training pack)
         slot = (prec, bool(log_sampling_xyz), bool(log_sampling_dir), dev)
         key = self.param_key()
         pk = self._packed.get(slot)

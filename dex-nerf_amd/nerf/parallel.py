@@ -49,6 +49,19 @@ def render_sharded(render_fn, ray_origins, ray_directions):
     return tuple(gathered)
 
 
+def _avg_in_collective():
+    """RCCL averages inside the collective (ReduceOp.AVG); gloo has no AVG: sum, then one division."""
+    return dist.get_backend() == "nccl"
+
+
+def _all_reduce_avg(t, world):
+    if _avg_in_collective():
+        dist.all_reduce(t, op=dist.ReduceOp.AVG)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.div_(world)
+
+
 class FlatGradBucket:
     """The gradients of the coarse + fine nets as slices of ONE contiguous fp32 buffer (2 x 595,844 floats = 4.77 MB for
     D8/W256), exchanged with one all-reduce per network per step.
@@ -90,11 +103,14 @@ class FlatGradBucket:
                 p.grad = v
 
     def zero(self):
-        """Start of a step: one memset; re-point any `.grad` something else dropped or replaced."""
+        """One memset; re-point any `.grad` something else dropped or replaced.  May be called before the forward or - as the
+        training loops do (train_dexnerf.py iteration(), bench.py step()) - between the forward and `loss.backward()`: the count
+        of forwards whose backward is still to come (`_pending`) is NOT touched here, it is the step's own bookkeeping and is
+        reset where the step ends (all_reduce_mean).  An exchange still in flight would race with the memset: refuse."""
+        if self._works:
+            raise RuntimeError("FlatGradBucket.zero(): a segment's all-reduce is still in flight - call all_reduce_mean() first")
         self._attach()
         self.flat.zero_()
-        self._pending = [0] * len(self.modules)
-        self._works = {}
 
     def segment(self, idx):
         lo, hi = self.segments[idx]
@@ -105,24 +121,27 @@ class FlatGradBucket:
         rank, world = world_info()
         if world == 1 or not self.overlap or idx in self._works:
             return
-        self._works[idx] = dist.all_reduce(self.segment(idx), op=dist.ReduceOp.SUM, async_op=True)
+        op = dist.ReduceOp.AVG if _avg_in_collective() else dist.ReduceOp.SUM
+        self._works[idx] = dist.all_reduce(self.segment(idx), op=op, async_op=True)
 
     def all_reduce_mean(self):
         """Finish the step's exchange: afterwards every `.grad` holds the mean over the ranks."""
         rank, world = world_info()
+        self._pending = [0] * len(self.modules)   # the step is over: a forward whose backward never ran must not block the next one
         if world == 1:
             return
         if not self._works:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)          # nothing was launched early: one flat message
+            _all_reduce_avg(self.flat, world)                         # nothing was launched early: one flat message
         else:
             for idx in range(len(self.modules)):
                 work = self._works.get(idx)
                 if work is None:
-                    dist.all_reduce(self.segment(idx), op=dist.ReduceOp.SUM)
+                    _all_reduce_avg(self.segment(idx), world)
                 else:
                     work.wait()
+                    if not _avg_in_collective():
+                        self.segment(idx).div_(world)
         self._works = {}
-        self.flat.div_(world)
 
 
 class _GradSink:
@@ -134,6 +153,11 @@ class _GradSink:
     def views(self, module):
         """[(dW, db)] views of the bucket in module.linear_modules() order, or None when a `.grad` is not (any more) the
         bucket's view - the caller then returns gradients to autograd the ordinary way."""
+        if self.idx in self.bucket._works:
+            # gradient accumulation (a second backward before all_reduce_mean) with world > 1: this segment has already been
+            # handed to the collective - adding to it now would race with the exchange and stay un-averaged
+            raise RuntimeError("FlatGradBucket: a backward reached a segment whose all-reduce is already in flight; the overlapped "
+                               "exchange needs exactly one loss.backward() per step (use overlap=False to accumulate micro-batches)")
         out = []
         for lin in module.linear_modules():
             w, b = lin.weight.grad, lin.bias.grad

@@ -88,6 +88,7 @@ def depth_error_img(D_est_tensor, D_gt_tensor, mask, abs_thres=1., dilate_radius
 
 # ---- hot path ------------------------------------------------------------------------------------------
 import os as _os
+_FP16_RENDER_DISABLED = [False]   # set once an fp16 render overflowed (see predict_and_render_radiance)
 _STAGEWISE_TRAINING = [bool(int(_os.environ.get("DEXNERF_STAGEWISE_TRAINING", "0")))]   # tests flip this to compare the two routes
 
 
@@ -181,10 +182,27 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mo
             draws["noise_f"] = randn(n, nc + nf)
         lx = encode_position_fn.log_sampling
         ld = encode_direction_fn.log_sampling if use_viewdirs else True
-        pc = model_coarse.packed(lx, ld)
-        pf = model_fine.packed(lx, ld) if fine else None
-        rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f, dex = _ops.render_rays(
-            pc, pf, ray_batch, nc, nf if fine else 0, lindisp, std, white, thres, draws)
+        # bf16 modes: a no-grad render runs the fp16 instance of the kernel (_ops.set_render_policy), guarded against fp16's
+        # range by the non-finite count the compositing passes leave in the workspace; stream capture cannot read it back
+        # (no synchronisation inside a capture), so captured renders stay in the configured precision
+        prec = _ops.render_precision()
+        guarded = (prec != _ops._precision and not torch.cuda.is_current_stream_capturing() and not _FP16_RENDER_DISABLED[0]
+                   and model_coarse.num_encoding_fn_xyz == 10 and (not fine or model_fine.num_encoding_fn_xyz == 10))   # fp16 instances: L_xyz = 10
+        if not guarded:
+            prec = _ops._precision
+        pc = model_coarse.packed(lx, ld, precision=prec)
+        pf = model_fine.packed(lx, ld, precision=prec) if fine else None
+        maps = _ops.render_rays(pc, pf, ray_batch, nc, nf if fine else 0, lindisp, std, white, thres, draws)
+        if guarded and _ops.render_nonfinite_count() > 0:
+            import warnings
+            warnings.warn("nerf: an fp16 render produced non-finite raw radiance-field values (a hidden activation beyond fp16's "
+                          "range, 65504); this render is repeated in bf16 and every later one in this process runs in bf16 "
+                          "(nerf.set_render_policy)", RuntimeWarning, stacklevel=2)
+            _FP16_RENDER_DISABLED[0] = True
+            pc = model_coarse.packed(lx, ld)
+            pf = model_fine.packed(lx, ld) if fine else None
+            maps = _ops.render_rays(pc, pf, ray_batch, nc, nf if fine else 0, lindisp, std, white, thres, draws)
+        rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f, dex = maps
         dex_list = [] if dex is None else [dex[k] for k in range(dex.shape[0])]
         return tuple([rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f] + dex_list)
 

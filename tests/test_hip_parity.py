@@ -28,6 +28,16 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def _renders_in_the_named_precision():
+    """Tests that name 'bf16' test the bf16 kernels: no-grad renders stay in bf16 here.  The default policy (fp16 renders under
+    the bf16 modes, with the overflow guard) has its own tests, which set it explicitly."""
+    import nerf
+    nerf.set_render_policy("bf16")
+    yield
+    nerf.set_render_policy(None)
+
+
 def G(x, dev):
     return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 
@@ -1076,12 +1086,24 @@ def dex_agreement(dex, dex_ref, tol_scale=TOL):
     return float((miss <= tol_scale * np.abs(dex_ref).max()).mean()), float(miss.max())
 
 
+def _record_measurement(key, values):
+    """Measured figures behind a gate, appended to gpurun_out/test_measurements.jsonl (read back after a GPU run to keep the
+    floors just under what the kernels deliver)."""
+    import json
+    out = os.path.join(REPO, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "test_measurements.jsonl"), "a") as f:
+        f.write(json.dumps({"test": key, **{k: float(v) for k, v in values.items()}}) + "\n")
+
+
 def psnr_db(a, b, peak=1.0):
     mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
     return float(10.0 * np.log10(peak * peak / max(mse, 1e-14)))
 
 
-@pytest.mark.parametrize("precision,rgb_floor,depth_floor,dex_floor", [("bf16", 40.0, 35.0, 0.95), ("fp16", 55.0, 50.0, 0.97)])
+# floors just under the measured figures (bf16 41.6 dB / 37.0 dB / 0.981, fp16 57.5 / 53.7 / 0.9974): a regression that doubles the
+# Dex misses, or costs half a dB, fails
+@pytest.mark.parametrize("precision,rgb_floor,depth_floor,dex_floor", [("bf16", 41.0, 36.5, 0.975), ("fp16", 57.0, 53.0, 0.996)])
 def test_headline_kernel_16bit_against_reference_golden(golden, dev, precision, rgb_floor, depth_floor, dex_floor):
     """What bench.py times - D8/W256, 64+128, the 48-points-per-wave 16-bit kernel - end to end on the rays of the
     reference-recorded golden `render_d8w256_val` (192 rays; fp32 reference outputs): rgb PSNR, depth PSNR (peak = far - near
@@ -1123,9 +1145,161 @@ def test_headline_kernel_16bit_against_reference_golden(golden, dev, precision, 
     sig_err = rel_err(C(rf16)[..., 3], g["rf_fine"][..., 3])
     print(f"{precision} D8/W256 64+128 vs reference golden: rgb {rgb_psnr:.1f} dB, depth {depth_psnr:.1f} dB, Dex agreement "
           f"{frac:.4f} (worst miss {worst:.3f} m); fixed-depth Dex agreement {sfrac:.4f} (worst {sworst:.3f} m), sigma rel err {sig_err:.2e}")
+    _record_measurement(f"headline_{precision}", dict(rgb_psnr=rgb_psnr, depth_psnr=depth_psnr, dex_agree=frac, dex_worst_m=worst,
+                                                     fixed_depth_dex_agree=sfrac, sigma_rel_err=sig_err))
     assert rgb_psnr > rgb_floor and depth_psnr > depth_floor
     assert frac > dex_floor and sfrac > dex_floor
     assert np.array_equal(C(dex32), g["vf_dex"])  # the readout itself is exact on the golden sigma
+
+
+def test_bf16_mode_renders_in_guarded_fp16_by_default(golden, dev):
+    """nerf.set_precision('bf16') + the default render policy: a no-grad render runs the fp16 instance of the kernel (the Dex depth
+    sweep reads validation renders: reference train_dexnerf_rgb.py:391-408, nerf/volume_rendering_utils.py:51-58) - it equals the
+    'fp16' mode's render bit for bit and differs from the pure-bf16 one; training stays on the bf16 kernels (same loss as with the
+    policy off).  The guard: weights that drive a hidden activation beyond fp16's range (65504) make the raw radiance field
+    non-finite - the compositing passes count that, the render is repeated in bf16 (finite) with ONE warning, and the policy
+    stays off for the rest of the process."""
+    import warnings
+
+    import nerf
+    from nerf import train_utils
+    name = "render_d8w256_val"
+    g = golden(name)
+    mkw, wfn, rkw = CASES[name]
+    mc, mf = make_models(mkw, *wfn(), dev)
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    ro, rd = G(g["ro"], dev)[None], G(g["rd"], dev)[None]
+
+    def render():
+        with torch.no_grad():
+            return nerf.run_one_iter_of_nerf(1, ro.shape[1], 1.0, mc, mf, ro, rd, make_cfg(rkw), mode="validation",
+                                             encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=list(M_THRES))
+    try:
+        nerf.set_precision("fp16")
+        ref16 = render()
+        nerf.set_precision("bf16")
+        nerf.set_render_policy("bf16")
+        pure = render()
+        nerf.set_render_policy("fp16")
+        assert nerf.get_render_policy() == "fp16"
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            pol = render()
+        for a, b in zip(pol, ref16):
+            assert torch.equal(a, b)
+        assert not torch.equal(pol[3], pure[3])
+        # training is untouched by the policy
+        losses = []
+        for policy in ("fp16", "bf16"):
+            nerf.set_render_policy(policy)
+            torch.manual_seed(3)
+            out = nerf.run_one_iter_of_nerf(1, ro.shape[1], 1.0, mc, mf, ro[0], rd[0], make_cfg(rkw), mode="train",
+                                            encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=list(M_THRES))
+            assert out[3].requires_grad
+            losses.append(float(out[3].detach().double().sum()))
+        assert losses[0] == losses[1]
+        # the guard
+        nerf.set_render_policy("fp16")
+        with torch.no_grad():
+            mf.layers_xyz[2].weight.mul_(1.0e6)   # hidden activations ~1e6: beyond fp16 (65504), nothing for bf16
+        nerf.models.mark_parameters_updated()
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            guarded = render()
+            again = render()
+        assert sum("fp16 render produced non-finite" in str(w.message) for w in caught) == 1
+        assert train_utils._FP16_RENDER_DISABLED[0]
+        nerf.set_render_policy("bf16")
+        pure_big = render()
+        for a, b, c in zip(guarded, pure_big, again):
+            assert torch.equal(a, b) and torch.equal(c, b)
+        assert bool(torch.isfinite(guarded[3]).all())
+    finally:
+        train_utils._FP16_RENDER_DISABLED[0] = False
+        nerf.set_precision("fp32")
+
+
+def test_fp32_mode_on_16384_rays_of_the_bench_scene(dev):
+    """The exact-fp32 mode at the size bench.py samples (16,384 rays of the 400x400 bench view, D8/W256, 64+128) against the CPU
+    oracle.  North_star's 1e-4 is met on all but a handful of rays: an ulp in a coarse sigma moves a resampled depth across a
+    density edge there - two fp32-level evaluations of the REFERENCE's own code differ by 6.0e-4 on 3 of these rays
+    (profiles/r02_fp32_noise_floor.md); measured here: 4 rays over 1e-4, max 8.4e-4, p99.9 1.3e-5.  Gated: at most 8 rays over
+    1e-4, p99.9 <= 2e-5 on every map, Dex-depth agreement >= 0.9999."""
+    import bench
+    import nerf
+    models, cfg, ro, rd, ex, ed = bench.build_scene(dev, 0)
+    with torch.no_grad():
+        out = nerf.run_one_iter_of_nerf(bench.H, bench.W, 1.0, models[0], models[1], ro, rd, cfg, mode="validation",
+                                        encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=bench.M_THRES)
+    cb, sel, ref = bench.cpu_baseline(16384)
+    idx = torch.from_numpy(sel).to(dev)
+    worst = {}
+    for i, nm in ((0, "rgb_coarse"), (3, "rgb_fine"), (4, "depth_fine"), (5, "acc_fine")):
+        a = C(out[i].reshape(bench.H * bench.W, -1)[idx]).astype(np.float64)
+        b = ref[i].numpy().reshape(len(sel), -1).astype(np.float64)
+        per_ray = np.abs(a - b).max(-1) / np.abs(b).max()
+        worst[nm] = (int((per_ray > 1e-4).sum()), float(np.quantile(per_ray, 0.999)), float(per_ray.max()))
+        assert worst[nm][0] <= 8 and worst[nm][1] <= 2e-5, (nm, worst[nm])
+    dex = bench.dex_agreement(out, ref, sel, dev)
+    _record_measurement("fp32_16384", dict(rgb_fine_over=worst["rgb_fine"][0], rgb_fine_p999=worst["rgb_fine"][1],
+                                            rgb_fine_max=worst["rgb_fine"][2], dex_agree=dex["agree_frac"], cpu_rays_per_s=cb["value"]))
+    assert dex["agree_frac"] >= 0.9999, dex
+
+
+def test_config5_training_step_fp32_luminance_head_against_oracle_autograd(dev, monkeypatch):
+    """BASELINE.json configs[4] as configured: 128 coarse + 256 fine samples, exact fp32, D8/W256 nets, the IR loss head (MSE on
+    the luminance 0.299 r + 0.587 g + 0.114 b of both passes: reference train_nerf_ir.py:260-263), perturbed sampling + density
+    noise with the same injected draws on both sides - one training step on the fused kernels against autograd through the CPU
+    oracle: loss at 1e-4, every parameter gradient of both networks at 1e-3 (the gradient tolerance of
+    test_train_step_matches_reference)."""
+    import nerf
+    from nerf import synthetic as syn
+    from oracle import nerf_oracle as oc
+    kw = CASES["render_d8w256_val"][0]
+    sd_c, sd_f = CASES["render_d8w256_val"][1]()
+    mc, mf = make_models(kw, sd_c, sd_f, dev)
+    h = w = 400
+    nc, nf, n = 128, 256, 96
+    e_mat, k_mat = torch.from_numpy(syn.scene_pose(9)), torch.from_numpy(syn.intrinsic(h, w))
+    ro, rd = nerf.get_ray_bundle(h, w, float(k_mat[0, 0]), e_mat.to(dev), k_mat.to(dev))
+    sel = torch.from_numpy(syn.select_rays(h, w, n, seed=77)).to(dev)
+    ro, rd = ro.reshape(-1, 3)[sel].contiguous(), rd.reshape(-1, 3)[sel].contiguous()
+    gen = torch.Generator().manual_seed(123)
+    draws = dict(t_rand=torch.rand(n, nc, generator=gen), noise_c=torch.randn(n, nc, generator=gen),
+                 u=torch.rand(n, nf, generator=gen), noise_f=torch.randn(n, nc + nf, generator=gen))
+    target = torch.rand(n, 3, generator=gen)
+    rkw = dict(num_coarse=nc, num_fine=nf, near=2.0, far=6.0, perturb=True, noise_std=0.2)
+
+    def lum(t):
+        return 0.299 * t[..., 0] + 0.587 * t[..., 1] + 0.114 * t[..., 2]
+    q_rand = [draws["t_rand"].to(dev), draws["u"].to(dev)]
+    q_randn = [draws["noise_c"].to(dev), draws["noise_f"].to(dev)]
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: q_rand.pop(0))
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: q_randn.pop(0))
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    out = nerf.run_one_iter_of_nerf(h, w, 1.0, mc, mf, ro, rd, make_cfg(rkw, 4096), mode="train", encode_position_fn=ex,
+                                    encode_direction_fn=ed, m_thres_cand=list(M_THRES))
+    monkeypatch.undo()
+    assert not q_rand and not q_randn
+    tgt = target.to(dev)
+    loss = nerf.img2mse(lum(out[0]), lum(tgt)) + nerf.img2mse(lum(out[3]), lum(tgt))
+    loss.backward()
+    # the oracle, with autograd through its own nn.functional composition
+    tsd_c, tsd_f = oc.to_torch_sd(sd_c, requires_grad=True), oc.to_torch_sd(sd_f, requires_grad=True)
+    cfg_o = oc.RenderCfg(chunksize=4096, m_thres=M_THRES, num_coarse=nc, num_fine=nf, near=2.0, far=6.0, perturb=True, noise_std=0.2)
+    mcfg = oc.ModelCfg(**kw)
+    ref = oc.run_one_iter(ro.cpu(), rd.cpu(), tsd_c, tsd_f, mcfg, mcfg, cfg_o, draws=draws)
+    mse = torch.nn.functional.mse_loss
+    loss_ref = mse(lum(ref[0]), lum(target)) + mse(lum(ref[3]), lum(target))
+    loss_ref.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    worst = 0.0
+    for model, tsd in ((mc, tsd_c), (mf, tsd_f)):
+        for k, p in model.named_parameters():
+            err = rel_err(C(p.grad), tsd[k].grad.numpy())
+            worst = max(worst, err)
+            assert err < 1e-3, (k, err)
+    _record_measurement("config5_train_fp32_ir", dict(loss=loss.item(), loss_ref=loss_ref.item(), worst_grad_rel_err=worst))
 
 
 @pytest.mark.parametrize("nc,nf,tag", [(64, 192, "config 4 sampling"), (128, 256, "config 5 sampling")])
@@ -1566,6 +1740,10 @@ def test_training_leaves_the_inference_stream_stale_and_a_render_refreshes_it(de
         out = nerf.run_network(m, pts, rays, 1 << 20, ex, ed)                 # (a training forward on the updated parameters)
         pk = m.packed(train=True)
         assert pk.key48 != pk.key                                             # the inference stream is two optimizer steps old
+        # a caller that kept the packed object and renders with it directly would get the OLD weights: refused, not served
+        from nerf import _ops
+        with pytest.raises(RuntimeError, match="48-point inference stream is older"):
+            _ops.run_network_pts(pk, pts.reshape(-1, 3), vd, s)
         with torch.no_grad():
             after = nerf.run_network(m, pts, rays, 1 << 20, ex, ed)           # render: refreshes it
         assert m.packed().key48 == m.packed().key

@@ -132,6 +132,59 @@ def _case_flat_bucket_overlapped(rank, world, tmp):
     assert torch.equal(flat_w, torch.cat([p.detach().reshape(-1) for p in ref.params]))
 
 
+def _case_flat_bucket_zero_between_forward_and_backward(rank, world, tmp):
+    """The order the training loops really use (train_dexnerf.py iteration(), bench.py step()): forward (the autograd nodes count
+    themselves with forward_issued) -> bucket.zero() -> loss.backward() -> all_reduce_mean, with TWO ray chunks through each
+    network (num_random_rays > chunksize).  zero() must not forget the issued forwards: the fine segment's exchange may start only
+    after its LAST chunk's backward, or the second chunk's gradients race with the collective and stay un-averaged (replicas
+    diverge silently).  Also: a backward that reaches a segment already handed to the collective is refused (gradient
+    accumulation needs overlap=False), and zero() refuses to memset under an exchange in flight."""
+    from nerf import models, parallel
+    torch.manual_seed(11)
+    nets = [models.FlexibleNeRFModel(num_layers=3, hidden_size=32) for _ in range(2)]
+    ref_nets = [models.FlexibleNeRFModel(num_layers=3, hidden_size=32) for _ in range(2)]
+    for a, b in zip(nets, ref_nets):
+        b.load_state_dict(a.state_dict())
+    bucket = parallel.FlatGradBucket(nets, overlap=True)
+    ref = parallel.FlatGradBucket(ref_nets, overlap=False)
+    torch.manual_seed(90 + rank)
+    sinks = [m._grad_sink for m in nets]
+    for step in range(3):
+        xs = [torch.randn(8, nets[0].dim_xyz + nets[0].dim_dir) for _ in range(2)]
+        # forward of both chunks through both networks (coarse then fine per chunk, as predict_and_render_radiance does)
+        outs = []
+        for x in xs:
+            sinks[0].forward_issued(); sinks[1].forward_issued()
+            outs.append((nets[0](x), nets[1](x)))
+        bucket.zero()                                   # AFTER the forward, BEFORE the backward
+        assert bucket._pending == [2, 2]
+        # backward in autograd's order: last chunk first, fine before coarse inside a chunk
+        for c in (1, 0):
+            outs[c][1].pow(2).mean().backward()
+            sinks[1].views(nets[1])                      # what FusedNetFn.backward asks for before it accumulates
+            sinks[1].backward_done()
+            assert (1 in bucket._works) == (c == 0), (step, c)   # only after the LAST chunk
+            outs[c][0].pow(2).mean().backward()
+            sinks[0].views(nets[0])
+            sinks[0].backward_done()
+            assert (0 in bucket._works) == (c == 0), (step, c)
+        if step == 1:
+            with pytest.raises(RuntimeError, match="in flight"):
+                sinks[1].views(nets[1])                  # a further backward would race with the exchange
+            with pytest.raises(RuntimeError, match="in flight"):
+                bucket.zero()
+        bucket.all_reduce_mean()
+        assert bucket._pending == [0, 0] and not bucket._works
+        ref.zero()
+        for x in xs:
+            (ref_nets[0](x).pow(2).mean() + ref_nets[1](x).pow(2).mean()).backward()
+        ref.all_reduce_mean()
+        assert torch.allclose(bucket.flat, ref.flat, rtol=0, atol=1e-7), step
+        gathered = [torch.empty_like(bucket.flat) for _ in range(world)]
+        dist.all_gather(gathered, bucket.flat)
+        assert torch.equal(gathered[0], gathered[1])     # the replicas hold the same averaged gradient
+
+
 def _case_broadcast_invalidates_packed_cache(rank, world, tmp):
     """broadcast_parameters writes through .data (no version bump): the packed-weight cache key must change anyway, or a
     model that packed before the broadcast keeps serving its old weight stream on the non-source ranks."""
@@ -159,6 +212,10 @@ def test_flat_grad_bucket_world2(tmp_path):
 
 def test_flat_grad_bucket_overlapped_world2(tmp_path):
     _run("_case_flat_bucket_overlapped", tmp_path)
+
+
+def test_flat_grad_bucket_zero_between_forward_and_backward_world2(tmp_path):
+    _run("_case_flat_bucket_zero_between_forward_and_backward", tmp_path)
 
 
 def test_broadcast_invalidates_packed_cache_world2(tmp_path):

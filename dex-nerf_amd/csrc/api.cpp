@@ -103,8 +103,8 @@ extern "C" int dn_render_rays(const dn_mlp_desc* desc_coarse, const void* packed
     if (e != hipSuccess) { set_error("dn_render_rays: hipMemsetAsync: %s", hipGetErrorString(e)); return -static_cast<int>(e); }
   }
   if ((rc = dn_coarse_depths(rays, ray_stride, n_rays, num_coarse, lindisp, t_rand, w.z_c, stream))) return rc;
-  if ((rc = dn_run_network(desc_coarse, precision, packed_coarse, nullptr, nullptr, rays, ray_stride, w.z_c, n_rays,
-                           num_coarse, w.rf_c, stream)))
+  if ((rc = run_network_flagged(desc_coarse, precision, packed_coarse, nullptr, nullptr, rays, ray_stride, w.z_c, n_rays,
+                                num_coarse, w.rf_c, w.status + 1, stream)))
     return rc;
   const bool fine = num_fine > 0;
   // Dex depths come from the fine pass (train_utils.py:199-201); coarse-only renders report the coarse ones.
@@ -114,8 +114,8 @@ extern "C" int dn_render_rays(const dn_mlp_desc* desc_coarse, const void* packed
     return rc;
   if (!fine) return 0;
   if ((rc = dn_fine_depths(w.z_c, w.w_c, u, n_rays, num_coarse, num_fine, w.z_f, nullptr, stream))) return rc;
-  if ((rc = dn_run_network(desc_fine, precision, packed_fine, nullptr, nullptr, rays, ray_stride, w.z_f, n_rays,
-                           num_coarse + num_fine, w.rf_f, stream)))
+  if ((rc = run_network_flagged(desc_fine, precision, packed_fine, nullptr, nullptr, rays, ray_stride, w.z_f, n_rays,
+                                num_coarse + num_fine, w.rf_f, w.status + 1, stream)))
     return rc;
   return volume_render_counting(w.rf_f, w.z_f, rays + 3, ray_stride, noise_f, noise_std, white_background, h_m_thres, n_thres,
                                 n_rays, num_coarse + num_fine, rgb_f, nullptr, acc_f, nullptr, depth_f, dex_f, w.status, stream);

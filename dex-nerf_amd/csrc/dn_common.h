@@ -39,6 +39,12 @@ int volume_render_counting(const float* rf, const float* z, const float* rd, int
                            float* disp, float* acc, float* weights, float* depth, float* dex, unsigned* nonfinite,
                            dn_stream_t stream);
 
+// mlp_fused.hip: dn_run_network with the fp16 range flag (a device word the 48-point fp16 kernel bumps when a hidden activation
+// left fp16's range; NULL = not wanted)
+int run_network_flagged(const dn_mlp_desc* desc, int precision, const void* packed, const float* pts, const float* viewdirs,
+                        const float* rays, int ray_stride, const float* z_vals, int64_t n_rays, int samples_per_ray, float* out,
+                        unsigned* range_flag, dn_stream_t stream);
+
 #define DN_REQUIRE(cond, ...)     \
   do {                            \
     if (!(cond)) {                \

@@ -100,6 +100,10 @@ struct FwdParams {
   int act_pieces, mask_words;   // (SAVE == 2, 8-bit saved tensors: act_pieces counts 1 KiB units = pairs of pieces)
   int slot_xyz, slot_dir, slot_layer1, slot_trunk0, slot_feat, slot_dirout;
   int save8;   // training forward: store the saved pieces at 8 bits (DN_PREC_BF16_S8)
+  // fp16 inference (48-point kernel): device word that receives +1 per wave whose hidden activations left fp16's range (an inf
+  // or NaN among the converted stage outputs), or NULL.  The raw output alone does not show it: the matrix pipe's NaN has its
+  // sign bit set, so the integer-max ReLU turns it into 0 and the rest of the network computes finite garbage.
+  unsigned* range_flag;
 };
 
 // ---- weight pipeline: LDS ring fed by LDS-DMA -------------------------------------------------------

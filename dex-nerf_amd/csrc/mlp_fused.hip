@@ -575,6 +575,11 @@ extern "C" size_t dn_mlp_packed_bytes(const dn_mlp_desc* desc, int precision) {
          (g48_supported(*desc, precision) ? g48_region_bytes(*desc) : 0);
 }
 
+extern "C" int dn_fp16_range_guard(const dn_mlp_desc* desc) {
+  if (validate_desc(desc, DN_PREC_F16)) return 0;
+  return (std::getenv("DEXNERF_G48_RUNTIME_SHAPE") == nullptr && std::getenv("DEXNERF_BF16_GEOM") == nullptr && g48_range_guard_complete(*desc)) ? 1 : 0;
+}
+
 extern "C" int dn_mlp_pack(const dn_mlp_desc* desc, int precision, const float* const* h_weights,
                            const float* const* h_biases, void* packed, dn_stream_t stream) {
   return dn_mlp_pack_parts(desc, precision, h_weights, h_biases, packed, DN_PACK_ALL, stream);
@@ -606,6 +611,14 @@ extern "C" int dn_mlp_pack_parts(const dn_mlp_desc* desc, int precision, const f
 extern "C" int dn_run_network(const dn_mlp_desc* desc, int precision, const void* packed, const float* pts,
                               const float* viewdirs, const float* rays, int ray_stride, const float* z_vals,
                               int64_t n_rays, int samples_per_ray, float* out, dn_stream_t stream) {
+  return dn::run_network_flagged(desc, precision, packed, pts, viewdirs, rays, ray_stride, z_vals, n_rays, samples_per_ray, out,
+                                 nullptr, stream);
+}
+
+// dn_run_network + the fp16 range flag of the 48-point kernel (FwdParams::range_flag; ignored by every other kernel)
+int dn::run_network_flagged(const dn_mlp_desc* desc, int precision, const void* packed, const float* pts,
+                            const float* viewdirs, const float* rays, int ray_stride, const float* z_vals,
+                            int64_t n_rays, int samples_per_ray, float* out, unsigned* range_flag, dn_stream_t stream) {
   FwdParams p;
   int rc = setup_params(desc, precision, packed, &p);
   if (rc) return rc;
@@ -623,6 +636,7 @@ extern "C" int dn_run_network(const dn_mlp_desc* desc, int precision, const void
   p.n_points = n_rays * samples_per_ray;
   p.S = samples_per_ray;
   p.out = out;
+  p.range_flag = range_flag;
   if (p.n_points == 0) return 0;
   return dispatch_forward(*desc, precision, p, as_stream(stream));
 }

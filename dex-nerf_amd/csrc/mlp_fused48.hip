@@ -57,9 +57,14 @@ constexpr int g48_issued(int q0, int q1) {
 // three MFMAs, read A(p+2); the next tile's bias read goes out right after the A read of step KT-2, i.e. between A(next
 // tile, 0) and A(next tile, 1) - so with a FIFO of P pieces the wait counts are P - 1 everywhere and P at k = KT-1; the
 // bias take at k = 0 waits with 1 (one A read was issued after the bias read), which also lands every older A read.
-template <int F, int NT_OUT, int KH, int KP, int POS0, bool LAST = false, bool SETTLE = true, int PAD = 0, int PH = kPhasePieces, class PipeT, class BH,
-          class BP, class Emit>
-__device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, unsigned bias_addr, unsigned next_addr, Emit&& emit) {
+// TRK (fp16 range guard, FwdParams::range_flag): 1 / 2 = fold the bit patterns of this stage's hidden INPUT pieces `bh` into the
+// running unsigned 16-bit maximum `*trk` (2: the input carries no ReLU, clear the sign bits first) - a few v_pk_max_u16 per output
+// tile, on registers that are live for the whole stage anyway (tracking the freshly converted outputs instead kept them live
+// behind a serial chain: 776 spilled registers).  A final pattern >= 0x7C00 is an infinity or a NaN.
+template <int F, int NT_OUT, int KH, int KP, int POS0, bool LAST = false, bool SETTLE = true, int PAD = 0, int PH = kPhasePieces, int TRK = 0,
+          class PipeT, class BH, class BP, class Emit>
+__device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, unsigned bias_addr, unsigned next_addr, Emit&& emit,
+                                            unsigned* trk = nullptr) {
   constexpr int PT = 3, KT = KH + KP;
   static_assert(KT >= 2, "the bias prefetch distance assumes at least two pieces per tile");
   static_for<NT_OUT>([&](auto nt_c) {
@@ -115,6 +120,25 @@ __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, 
     });
     __builtin_amdgcn_sched_barrier(0);
     static_for<PT>([&](auto t_c) { emit(nt_c, t_c, acc[decltype(t_c)::value]); });
+    if constexpr (F == 2 && TRK != 0) {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      constexpr int TOT = PT * KH * 4;   // input dwords of this wave
+      constexpr int Q0 = nt * TOT / NT_OUT, Q1 = (nt + 1) * TOT / NT_OUT;
+      static_for<Q1 - Q0>([&](auto q_c) {
+        constexpr int q = Q0 + decltype(q_c)::value;
+        const unsigned v = __builtin_bit_cast(u32x4, bh[q / (KH * 4)][(q / 4) % KH])[q % 4];
+        // opaque: written as plain max operations the optimiser reassociates the whole kernel's chain into one expression
+        // evaluated at the end of the tile loop - every stage's pieces stay live until then (hundreds of spilled registers)
+        unsigned t = *trk;
+        if constexpr (TRK == 2) {
+          unsigned tmp;
+          asm volatile("v_and_b32 %1, 0x7fff7fff, %2\n\tv_pk_max_u16 %0, %0, %1" : "+v"(t), "=&v"(tmp) : "v"(v));
+        } else {
+          asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(t) : "v"(v));
+        }
+        *trk = t;
+      });
+    }
   });
 #ifdef DN_PIPE_ASM_READS
   // run-time network shape: no read stays in flight across a stage boundary (control flow merges there: see Pipe::settle);
@@ -285,6 +309,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 #if defined(DN_G48_PRIO) && DN_G48_PRIO == 1   // static priority for the younger half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
+  unsigned trk = 0;   // fp16 instances: running maximum of the stage inputs' 16-bit patterns (run_stage48, TRK)
   int vset = 0;  // which view-direction rows hold this tile's directions (wave-uniform, flips every tile)
   const int n_tiles = static_cast<int>(p.n_tiles);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, vset ^= 1) {
@@ -357,9 +382,9 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         run_stage48<F, 1, KH, 0, 0, false, ST, 0, PH>(pipe, hx, no_pe, bias_at(bias_tile), 0u, [&](auto, auto t_c, const f32x4& acc) {
           out4[decltype(t_c)::value][3] = acc[0];  // row 0 lives in lane group 0, register 0
         });
-        run_stage48<F, NT, KH, 0, KH % PH, false, ST, 0, PH>(pipe, hx, no_pe, bias_at(bias_tile + 1), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
+        run_stage48<F, NT, KH, 0, KH % PH, false, ST, 0, PH, 1>(pipe, hx, no_pe, bias_at(bias_tile + 1), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
           emit48<F, true, decltype(nt_c)::value>(acc, hy[decltype(t_c)::value]);
-        });
+        }, &trk);
         bias_tile += NT + 1;
         // ---- view-direction encoding (one 32-deep piece per point group) ----
         // fenced on both sides: interleaved into the fc_feat MFMAs its temporaries push finished activation pieces to scratch
@@ -393,9 +418,9 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 #pragma unroll
         for (int t = 0; t < PT; ++t) ped[t] = *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes);
         auto pe_dir = [&](int t, int) { return ped[t]; };
-        run_stage48<F, NT / 2, KH, KDP, POS_D, false, ST, 0, PH>(pipe, hy, pe_dir, bias_at(bias_tile), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
+        run_stage48<F, NT / 2, KH, KDP, POS_D, false, ST, 0, PH, 1>(pipe, hy, pe_dir, bias_at(bias_tile), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
           emit48<F, true, decltype(nt_c)::value>(acc, bg[decltype(t_c)::value]);
-        });
+        }, &trk);
         bias_tile += NT / 2;
         // ---- fc_rgb (models.py:253) ----
         constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % PH;
@@ -403,19 +428,19 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         static_assert(END <= PH && (END - 1) / kPhasePieces == POS_R / kPhasePieces, "the tail stays inside one phase");
         constexpr int PAD_R = (kPhasePieces - END % kPhasePieces) % kPhasePieces;
         static_assert((END + PAD_R) % PH == 0, "a tile pass is a whole number of barrier periods");
-        run_stage48<F, 1, KH / 2, 0, POS_R, true, ST, PAD_R, PH>(pipe, bg, no_pe, bias_at(bias_tile), bias_at(0), [&](auto, auto t_c, const f32x4& acc) {
+        run_stage48<F, 1, KH / 2, 0, POS_R, true, ST, PAD_R, PH, 1>(pipe, bg, no_pe, bias_at(bias_tile), bias_at(0), [&](auto, auto t_c, const f32x4& acc) {
           constexpr int t = decltype(t_c)::value;
           out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2];
-        });
+        }, &trk);
         if constexpr (PAD_R != 0) pipe.template skip<END, PAD_R, PH>();   // (settles at its end)
         else pipe.settle();
       } else {
         // ---- fc_out (models.py:256) ----
         static_assert(PH == kPhasePieces, "no-viewdirs nets run the every-phase barrier");
-        run_stage48<F, 1, KH, 0, 0, true, ST, (kPhasePieces - KH % kPhasePieces) % kPhasePieces>(pipe, hx, no_pe, bias_at(bias_tile), bias_at(0), [&](auto, auto t_c, const f32x4& acc) {
+        run_stage48<F, 1, KH, 0, 0, true, ST, (kPhasePieces - KH % kPhasePieces) % kPhasePieces, kPhasePieces, 1>(pipe, hx, no_pe, bias_at(bias_tile), bias_at(0), [&](auto, auto t_c, const f32x4& acc) {
           constexpr int t = decltype(t_c)::value;
           out4[t][0] = acc[0]; out4[t][1] = acc[1]; out4[t][2] = acc[2]; out4[t][3] = acc[3];
-        });
+        }, &trk);
         if constexpr (KH % kPhasePieces != 0) pipe.template skip<KH % kPhasePieces, kPhasePieces - KH % kPhasePieces>();
         else pipe.settle();
       }
@@ -438,10 +463,10 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
           for (int t = 0; t < PT; ++t)
 #pragma unroll
             for (int k = 0; k < KXP; ++k) pe[t][k] = pe_xyz(t, k);
-          run_stage48<F, NT, KH, KXP, 0, false, false, 0, PH>(pipe, bin, [&](int t, int k) { return pe[t][k]; }, bias_at(bias_tile), 0u, emit);
+          run_stage48<F, NT, KH, KXP, 0, false, false, 0, PH, (i == 0 ? 2 : 1)>(pipe, bin, [&](int t, int k) { return pe[t][k]; }, bias_at(bias_tile), 0u, emit, &trk);
 #endif
         } else {
-          run_stage48<F, NT, KH, 0, 0, false, false, 0, PH>(pipe, bin, no_pe, bias_at(bias_tile), 0u, emit);
+          run_stage48<F, NT, KH, 0, 0, false, false, 0, PH, (i == 0 ? 2 : 1)>(pipe, bin, no_pe, bias_at(bias_tile), 0u, emit, &trk);
         }
         bias_tile += NT;
       });
@@ -456,8 +481,11 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         auto emit = [&](auto nt_c, auto t_c, const f32x4& acc) {
           emit48<F, true, decltype(nt_c)::value>(acc, bout[decltype(t_c)::value]);
         };
-        if ((p.skip_mask >> i) & 1u) run_stage48<F, NT, KH, KXP, 0>(pipe, bin, pe_xyz, bias_at(bias_tile), 0u, emit);
-        else run_stage48<F, NT, KH, 0, 0>(pipe, bin, no_pe, bias_at(bias_tile), 0u, emit);
+        // (the range tracker costs the run-time-shape W = 256 instance 315 spilled registers: it tracks in the heads only, and
+        // dn_fp16_range_guard() says so)
+        constexpr int TRK_RT = W == 128 ? 2 : 0;
+        if ((p.skip_mask >> i) & 1u) run_stage48<F, NT, KH, KXP, 0, false, true, 0, kPhasePieces, TRK_RT>(pipe, bin, pe_xyz, bias_at(bias_tile), 0u, emit, &trk);
+        else run_stage48<F, NT, KH, 0, 0, false, true, 0, kPhasePieces, TRK_RT>(pipe, bin, no_pe, bias_at(bias_tile), 0u, emit, &trk);
         bias_tile += NT;
       };
       int i = 0;
@@ -490,6 +518,10 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if constexpr (F == 2) {
+    const bool out_of_range = (trk & 0xFFFFu) >= 0x7C00u || (trk >> 16) >= 0x7C00u;
+    if (p.range_flag != nullptr && __ballot(out_of_range) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(p.range_flag, 1u);
+  }
 #ifdef DN_STAMP
   if ((threadIdx.x & 63) == 0) {
     unsigned* d = q.dbg + (blockIdx.x * WAVES + wave) * 16;
@@ -591,6 +623,16 @@ int launch_pack48(const dn_mlp_desc& d, int precision, const PackPtrs& ptrs, cha
   if (precision == DN_PREC_F16) hipLaunchKernelGGL(pack48_kernel<2>, dim3(512), dim3(256), 0, stream, L, ptrs, tabs, region);
   else hipLaunchKernelGGL(pack48_kernel<1>, dim3(512), dim3(256), 0, stream, L, ptrs, tabs, region);
   return check_launch("mlp_pack48");
+}
+
+// 1 when an fp16 launch of this network reports EVERY hidden activation that leaves fp16's range (FwdParams::range_flag): the
+// fixed-shape instances and the W = 128 ones; the run-time-shape W = 256 instance tracks only the head stages
+bool g48_range_guard_complete(const dn_mlp_desc& d) {
+  if (!g48_supported(d, DN_PREC_F16)) return false;
+  NetLayout L;
+  build_layout48(d, &L);
+  const bool paper = d.hidden_size == 256 && d.num_layers == 8 && L.skip_mask == 0x10u && d.use_viewdirs;
+  return paper || d.hidden_size == 128;
 }
 
 int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in, const char* region, hipStream_t stream) {

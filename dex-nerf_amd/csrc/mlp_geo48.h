@@ -114,6 +114,7 @@ inline size_t g48_region_bytes(const dn_mlp_desc& d) {
   return static_cast<size_t>(L.bias_bytes) + kG48TableBytes + static_cast<size_t>(L.total_pieces) * kPieceBytes;
 }
 
+bool g48_range_guard_complete(const dn_mlp_desc& d);
 int launch_pack48(const dn_mlp_desc& d, int precision, const PackPtrs& ptrs, char* region, hipStream_t stream);
 int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p, const char* region, hipStream_t stream);
 

@@ -57,6 +57,13 @@ def render_precision():
     return _precision
 
 
+def fp16_range_guard(model):
+    """True when an fp16 render of this FlexibleNeRFModel reports every hidden activation that leaves fp16's range
+    (dn_fp16_range_guard: the kernel instances that carry the tracker) - the condition for the fp16 render policy."""
+    desc = MlpDesc(**{k: int(v) for k, v in model.desc_kwargs().items()})
+    return bool(lib().dn_fp16_range_guard(ctypes.byref(desc)))
+
+
 def get_precision():
     if _save8 and _precision == _hip.PREC_BF16:
         return "bf16-s8"
@@ -486,9 +493,11 @@ def render_rays(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, noise_s
 
 
 def render_nonfinite_count(ws=None):
-    """Status word of the last dn_render_rays call on this stream (synchronises): non-finite raw radiance-field samples."""
+    """Status block of the last dn_render_rays call on this stream (synchronises): non-finite raw radiance-field samples met
+    by the compositing passes + waves of the fp16 network kernel that saw an activation leave fp16's range."""
     ws = render_rays.last_workspace if ws is None else ws
-    return int(ws[ws.numel() - 256: ws.numel() - 252].view(torch.int32).item())
+    words = ws[ws.numel() - 256: ws.numel() - 248].view(torch.int32).tolist()
+    return int(words[0]) + int(words[1])
 
 
 # ---- predict_and_render_radiance under autograd: one C call forward, one (or two halves) backward ----------------------

@@ -187,7 +187,7 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mo
         # (no synchronisation inside a capture), so captured renders stay in the configured precision
         prec = _ops.render_precision()
         guarded = (prec != _ops._precision and not torch.cuda.is_current_stream_capturing() and not _FP16_RENDER_DISABLED[0]
-                   and model_coarse.num_encoding_fn_xyz == 10 and (not fine or model_fine.num_encoding_fn_xyz == 10))   # fp16 instances: L_xyz = 10
+                   and _ops.fp16_range_guard(model_coarse) and (not fine or _ops.fp16_range_guard(model_fine)))
         if not guarded:
             prec = _ops._precision
         pc = model_coarse.packed(lx, ld, precision=prec)

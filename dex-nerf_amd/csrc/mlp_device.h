@@ -442,7 +442,7 @@ struct Pipe {
 
   // Padding pieces (the stream is padded to whole phases): advance the FIFO over N pieces starting at position
   // POS without issuing MFMAs, so the next tile pass starts again at position 0 of a fresh phase.
-  template <int POS, int N, int PH = kPhasePieces>
+  template <int POS, int N, int PH = kPhasePieces, bool BIAS = true>
   __device__ __forceinline__ void skip() {
     static_for<N>([&](auto i_c) {
       constexpr int pos = POS + decltype(i_c)::value;
@@ -457,7 +457,7 @@ struct Pipe {
 #endif
     });
 #ifdef DN_PIPE_ASM_READS
-    settle();
+    settle<BIAS>();
 #endif
   }
 
@@ -506,16 +506,22 @@ struct Pipe {
   // flow merges (the trunk's run-time layer loop, the skip / no-skip branch, the tile loop) it may copy the FIFO registers
   // (phi copies) - before the data has arrived, if a read were still in flight there.  Called at the end of every stage
   // and after the padding pieces: one exposed LDS round trip per stage (12 per 1184 pieces).
+  template <bool BIAS = true>   // BIAS = false: a stream without bias rows (the backward chain) - bias_nxt is not a live register
   __device__ __forceinline__ void settle() {
 #ifdef DN_EXP_NOSETTLE   // timing experiment only (UNSAFE: phi copies may read fragments in flight)
     return;
 #endif
     static_assert(kPrefetch >= 2 && kPrefetch <= 4, "settle() names every FIFO entry");
+    if constexpr (!BIAS) {
+      static_assert(kPrefetch == 2, "the bias-less form is the 48-point pipeline's");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]));
+    } else
     if constexpr (kPrefetch == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bias_nxt));
     else if constexpr (kPrefetch == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(bias_nxt));
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[kPrefetch - 1]), "+v"(bias_nxt));
   }
 #else
+  template <bool BIAS = true>
   __device__ __forceinline__ void settle() {}
 #endif
 };
@@ -662,6 +668,24 @@ __device__ __forceinline__ void store16_uniform(const char* base, unsigned lane1
                : : [voff] "v"(voff), [data] "v"(data), [sbase] "s"(b) : "memory");
 }
 
+// The same store at (uniform base) + (uniform byte offset) + lane * 16, the offset added to the lane offset INSIDE the statement:
+// a kernel with a hundred stores per tile at different offsets of a few base pointers (the 48-point training kernels) otherwise
+// has every full 64-bit address formed ahead of time in scalar registers (83 spilled SGPRs), or in VGPRs.
+template <class V>
+__device__ __forceinline__ void store16_uniform_at(const char* base, unsigned byte_off, unsigned lane16, const V& val) {
+  static_assert(sizeof(V) == 16, "one dwordx4 per lane");
+  // `base` is the result of uniform_ptr() and `byte_off` scalar arithmetic on kernel arguments: both already live in SGPRs.
+  // (Passing them through v_readfirstlane again made hipcc keep VGPR copies of the scalars they are formed from across the
+  // whole tile loop - eight spilled registers in the backward kernel.)
+  const char* b = base;
+  const unsigned off = byte_off;
+  const unsigned voff = lane16;
+  const f32x4 data = __builtin_bit_cast(f32x4, val);
+  unsigned tmp;
+  asm volatile("v_add_u32 %[tmp], %[off], %[voff]\n\ts_nop 4\n\tglobal_store_dwordx4 %[tmp], %[data], %[sbase]" DN_STORE_POLICY "\n\ts_nop 1"
+               : [tmp] "=&v"(tmp) : [voff] "v"(voff), [off] "s"(off), [data] "v"(data), [sbase] "s"(b) : "memory");
+}
+
 // ---- 8-bit saved tensors (DN_PREC_BF16_S8): a bf16 B piece (8 values per lane) -> 8 bytes --------------------------
 // GRAD = false: e4m3 (activations, O(1)), saturated at +-448 (OCP e4m3 has no infinity: an unclamped overflow converts to NaN,
 // and one NaN activation poisons a whole layer's weight gradient); GRAD = true: e5m2 of value * scale, saturated at +-57344
@@ -686,6 +710,23 @@ __device__ __forceinline__ void piece_to_8bit(const bf16x8& v, float scale, unsi
     b = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], b, false); b = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], b, true);
   }
   w0 = static_cast<unsigned>(a); w1 = static_cast<unsigned>(b);
+}
+
+// 16 B per lane, per-lane global address -> LDS (M0 base + lane*16), as an opaque instruction: the counted waits of
+// the weight pipeline cover it (it is issued >= 3 phases before its data is read) and hipcc never waits on it.
+__device__ __forceinline__ void dma16_lanes(const void* src_lane, unsigned lds_addr) {
+  const unsigned lds = __builtin_amdgcn_readfirstlane(lds_addr);
+  const void* src = src_lane;
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %[keep], m0\n\t"
+      "s_mov_b32 m0, %[lds]\n\t"
+      "s_nop 1\n\t"
+      "global_load_lds_dwordx4 %[vaddr], off\n\t"
+      "s_mov_b32 m0, %[keep]"
+      : [keep] "=&s"(keep)
+      : [lds] "s"(lds), [vaddr] "v"(src)
+      : "memory");
 }
 
 // ---- positional encoding straight into B-piece layout -------------------------------------------------

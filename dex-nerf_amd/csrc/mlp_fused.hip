@@ -499,12 +499,12 @@ int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStrea
   if ((bf || hf) && geom48 && bf16_pt == 1 && p.act == nullptr && p.mode != 2 && p.n_points < (1LL << 31) - 1024 && g48_supported(d, precision))
     return launch_forward48(d, precision, p, p.packed + p.bias_bytes + static_cast<size_t>(p.total_pieces) * kPieceBytes, stream);
   if (p.act != nullptr && hf) { set_error("mlp_forward(train): fp16 is a render-only mode"); return DN_E_UNSUPPORTED; }
-  if (p.act != nullptr && p.save8) {   // training forward with 8-bit saved pieces (bf16 arithmetic)
-    if (!bf) { set_error("mlp_forward(train, 8-bit saved tensors): bf16 arithmetic only"); return DN_E_UNSUPPORTED; }
-    if (d.num_encoding_fn_xyz == 10 && d.hidden_size == 256) return launch_forward<256, 10, 4, 1, 1, 2>(p, stream);
-    if (d.num_encoding_fn_xyz == 10 && d.hidden_size == 128) return launch_forward<128, 10, 4, 1, 1, 2>(p, stream);
-    set_error("mlp_forward(train): no kernel instance for W=%d L_xyz=%d", d.hidden_size, d.num_encoding_fn_xyz);
-    return DN_E_UNSUPPORTED;
+  if (p.act != nullptr && p.save8) {   // training forward with 8-bit saved units: the 48-point geometry (mlp_fused48.hip, SAVE = 2)
+    if (!bf || p.mode == 2 || !g48_train_supported(d) || p.n_points >= (1LL << 31) - 1024) {
+      set_error("mlp_forward(train, 8-bit saved tensors): bf16 arithmetic, rays / points input, W in {128, 256}, L_xyz = 10, a depth the 48-point kernel holds in LDS");
+      return DN_E_UNSUPPORTED;
+    }
+    return launch_forward48(d, precision, p, p.packed + p.bias_bytes + static_cast<size_t>(p.total_pieces) * kPieceBytes, stream);
   }
   if (p.act != nullptr) {  // training forward: LX=10 nets, PT=1
     if (d.num_encoding_fn_xyz == 10 && d.hidden_size == 256)

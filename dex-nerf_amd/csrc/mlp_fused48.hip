@@ -7,168 +7,11 @@
 // Every A fragment read from LDS feeds three MFMAs: 384 points per pass of the weight stream instead of 256.
 // A-fragment FIFO of 2 pieces here (4 in the 32-point kernels): a piece lasts three MFMAs = 48 cycles, and the 256-VGPR
 // budget of two waves per SIMD is spent on the two 96-register activation sets
-#if defined(DN_PREFETCH) && !defined(DN_ABLATION_BUILD)
-#error "DN_PREFETCH is set by this file (the 48-point kernel's FIFO depth); a command-line value is an ablation hook (scripts/build_exp.sh)"
-#endif
-#ifdef DN_G48_PREFETCH   // (ablation hook, refused by mlp_device.h outside an ablation build)
-#define DN_PREFETCH DN_G48_PREFETCH
-#else
-#define DN_PREFETCH 2
-#endif
-#define DN_PREFETCH_SET_BY_KERNEL_SOURCE 1
-#define DN_PIPE_SCALAR_STATE 1   // ring bookkeeping in SGPRs: frees the VGPRs that were spilling (0.5 % on the launch)
-#ifndef DN_G48_COMPILER_READS    // (ablation hook: the r01 pipeline with compiler-issued reads and waits)
-#define DN_PIPE_ASM_READS 1      // A-fragment / bias LDS reads and their counted waits as opaque asm (mlp_device.h Pipe)
-#endif
-#ifndef DN_G48_SYMMETRIC_DMA     // (ablation hook: every wave fetches two pieces per phase, as in round 1)
-// Asymmetric roles.  The two waves of a SIMD do not share the matrix pipe fairly: the older one (waves 0-3) wins the
-// arbitration, runs a phase ahead and then sits at the phase barrier (s_memtime stamps, profiles/r02_fine_net_stalls.md:
-// ~640 cycles per phase against ~160 for waves 4-7), while the younger one - the critical path - also paid ~300 cycles per
-// phase of its own LDS-DMA issue.  So the waves with the slack fetch the whole weight stream (four pieces each) and
-// waves 4-7 issue MFMAs only.
-#define DN_PIPE_LEADER_DMA 1
-#endif
 #include <vector>
 
-#include "mlp_geo48.h"
+#include "mlp_stage48.h"
 
 namespace dn {
-
-// F = 1: bf16, 2: fp16 (Prec<F> of mlp_device.h): same MFMA rate and layouts
-template <int F>
-__device__ __forceinline__ f32x4 mfma48(typename Prec<F>::BPiece a, typename Prec<F>::BPiece b, f32x4 c) {
-  if constexpr (F == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
-// how many of the pieces [q0, q1) of the stream are ever fetched: all, except - behind the LAST stage of a pass, which ends at
-// position END - the PAD padding pieces nobody consumes
-template <bool LAST, int END, int PAD>
-constexpr int g48_issued(int q0, int q1) {
-  int n = 0;
-  for (int q = q0; q < q1; ++q) n += (LAST && q >= END && q < END + PAD) ? 0 : 1;
-  return n;
-}
-
-// One GEMM stage: NT_OUT 16-row output tiles, KH hidden pieces + KP encoding pieces per tile, three point groups.
-// bias_addr: LDS byte address of this lane group's 16 bytes of the stage's bias tile 0; the bias tiles of a tile pass are
-// contiguous in stream order, so "the next tile's bias" is the next 64 bytes, except after the last stage of the pass
-// (LAST): there it is next_addr (tile 0 of layer1).  Read pipeline (DN_PIPE_ASM_READS): step k of a tile = take A(p),
-// three MFMAs, read A(p+2); the next tile's bias read goes out right after the A read of step KT-2, i.e. between A(next
-// tile, 0) and A(next tile, 1) - so with a FIFO of P pieces the wait counts are P - 1 everywhere and P at k = KT-1; the
-// bias take at k = 0 waits with 1 (one A read was issued after the bias read), which also lands every older A read.
-// TRK (fp16 range guard, FwdParams::range_flag): 1 / 2 = fold the bit patterns of this stage's hidden INPUT pieces `bh` into the
-// running unsigned 16-bit maximum `*trk` (2: the input carries no ReLU, clear the sign bits first) - a few v_pk_max_u16 per output
-// tile, on registers that are live for the whole stage anyway (tracking the freshly converted outputs instead kept them live
-// behind a serial chain: 776 spilled registers).  A final pattern >= 0x7C00 is an infinity or a NaN.
-template <int F, int NT_OUT, int KH, int KP, int POS0, bool LAST = false, bool SETTLE = true, int PAD = 0, int PH = kPhasePieces, int TRK = 0,
-          class PipeT, class BH, class BP, class Emit>
-__device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, unsigned bias_addr, unsigned next_addr, Emit&& emit,
-                                            unsigned* trk = nullptr) {
-  constexpr int PT = 3, KT = KH + KP;
-  static_assert(KT >= 2, "the bias prefetch distance assumes at least two pieces per tile");
-  static_for<NT_OUT>([&](auto nt_c) {
-    constexpr int nt = decltype(nt_c)::value;
-    f32x4 acc[PT];
-    static_for<KT>([&](auto k_c) {
-      constexpr int k = decltype(k_c)::value;
-      constexpr int pos = POS0 + nt * KT + k;
-#if defined(DN_STAMP) && DN_STAMP == 1
-      if constexpr (pos % 4 == 0 && pos % kPhasePieces != 0) pipe.template substamp<(pos % kPhasePieces) / 4>();
-#endif
-      pipe.template at_position<PH, pos>();   // phase boundary (barrier + weight DMA) / mid-phase DMA, if this is one
-#ifdef DN_PIPE_ASM_READS
-      if constexpr (k == 0) {
-        const f32x4 b = pipe.template bias_take<1>();   // issued before A(pos + 1): one younger read may stay in flight
-#pragma unroll
-        for (int t = 0; t < PT; ++t) acc[t] = b;
-      }
-      // younger reads of ours than A(pos): the other FIFO entries - those that were issued at all (see PAD below) - plus
-      // the next tile's bias at k = KT - 1
-      constexpr int newer = g48_issued<LAST, POS0 + NT_OUT * KT, PAD>(pos + 1, pos + kPrefetch) + (k == KT - 1 ? 1 : 0);
-      const auto a = __builtin_bit_cast(typename Prec<F>::BPiece, pipe.template take<pos, newer>());
-#else
-      if constexpr (k == 0) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(pipe.ring + (bias_addr - pipe.ring_addr) + nt * 64);
-#pragma unroll
-        for (int t = 0; t < PT; ++t) acc[t] = b;
-      }
-      const auto a = __builtin_bit_cast(typename Prec<F>::BPiece, pipe.af[pos % kPrefetch]);
-#endif
-      static_for<PT>([&](auto t_c) {
-        constexpr int t = decltype(t_c)::value;
-        if constexpr (k < KH) acc[t] = mfma48<F>(a, bh[t][k], acc[t]);
-        else acc[t] = mfma48<F>(a, bp(t, k - KH), acc[t]);
-      });
-#ifdef DN_PIPE_ASM_READS
-      // PAD padding pieces follow the last stage of a pass (Pipe::skip): a read of one of THOSE would never be consumed, and
-      // a fragment nobody consumes is a dead value to the compiler - it reuses the registers while the read is in flight
-      if constexpr (g48_issued<LAST, POS0 + NT_OUT * KT, PAD>(pos + kPrefetch, pos + kPrefetch + 1) == 1) pipe.template prefetch<pos>();
-#else
-      pipe.template prefetch<pos>();
-#endif
-#ifdef DN_PIPE_ASM_READS
-      if constexpr (k == KT - 2) {
-        if constexpr (nt + 1 < NT_OUT) pipe.template bias_prefetch<(nt + 1) * 64>(bias_addr);
-        else if constexpr (LAST) pipe.template bias_prefetch<0>(next_addr);
-        else pipe.template bias_prefetch<NT_OUT * 64>(bias_addr);
-      }
-#else
-      __builtin_amdgcn_sched_group_barrier(0x008, PT, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#endif
-    });
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<PT>([&](auto t_c) { emit(nt_c, t_c, acc[decltype(t_c)::value]); });
-    if constexpr (F == 2 && TRK != 0) {
-      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      constexpr int TOT = PT * KH * 4;   // input dwords of this wave
-      constexpr int Q0 = nt * TOT / NT_OUT, Q1 = (nt + 1) * TOT / NT_OUT;
-      static_for<Q1 - Q0>([&](auto q_c) {
-        constexpr int q = Q0 + decltype(q_c)::value;
-        const unsigned v = __builtin_bit_cast(u32x4, bh[q / (KH * 4)][(q / 4) % KH])[q % 4];
-        // opaque: written as plain max operations the optimiser reassociates the whole kernel's chain into one expression
-        // evaluated at the end of the tile loop - every stage's pieces stay live until then (hundreds of spilled registers)
-        unsigned t = *trk;
-        if constexpr (TRK == 2) {
-          unsigned tmp;
-          asm volatile("v_and_b32 %1, 0x7fff7fff, %2\n\tv_pk_max_u16 %0, %0, %1" : "+v"(t), "=&v"(tmp) : "v"(v));
-        } else {
-          asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(t) : "v"(v));
-        }
-        *trk = t;
-      });
-    }
-  });
-#ifdef DN_PIPE_ASM_READS
-  // run-time network shape: no read stays in flight across a stage boundary (control flow merges there: see Pipe::settle);
-  // the fixed-shape instances are straight-line code from the top of a tile pass to its end and settle once, there
-  if constexpr (SETTLE) pipe.settle();
-#endif
-}
-
-// rows 4g..4g+3 of output tile NT -> elements (NT & 1) * 4 .. + 3 of B piece NT / 2 (g48_hidden_col)
-template <int F, bool RELU, int NT, class BO>
-__device__ __forceinline__ void emit48(const f32x4& acc, BO& bo) {
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef typename Prec<F>::Elem e16x2 __attribute__((ext_vector_type(2)));
-  typedef short s16x2 __attribute__((ext_vector_type(2)));
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 w = __builtin_bit_cast(u32x4, bo[NT / 2]);
-#pragma unroll
-  for (int d = 0; d < 2; ++d) {
-    const f32x2 f = {acc[2 * d], acc[2 * d + 1]};
-    e16x2 v = __builtin_convertvector(f, e16x2);  // one packed convert
-    if constexpr (RELU) {  // a negative bf16 / fp16 is a negative int16 (mlp_device.h make_piece)
-      s16x2 bits = __builtin_bit_cast(s16x2, v);
-      const s16x2 zero = {0, 0};
-      bits = __builtin_elementwise_max(bits, zero);
-      v = __builtin_bit_cast(e16x2, bits);
-    }
-    w[(NT & 1) * 2 + d] = __builtin_bit_cast(unsigned, v);
-  }
-  bo[NT / 2] = __builtin_bit_cast(typename Prec<F>::BPiece, w);
-}
 
 // one encoding slot: table entry = (frequency, phase in revolutions, identity weight, sine weight); the coordinate is a
 // compile-time element of the lane's rotated point (g48_pe_col).  No per-slot decode and no selects (per-lane compares
@@ -197,14 +40,20 @@ __device__ __forceinline__ void rotate3(const float (&x)[3], int g, float (&xr)[
 // ring bookkeeping stays in SGPRs, and the epilogue of a stage's last tile overlaps the next stage's first MFMAs like any
 // other tile's (measured: the 12 per-stage settles + merges of the run-time form cost 5 % of the launch).  DC = 0: everything
 // run-time (p.D, p.skip_mask, p.use_viewdirs), one settle per stage.
-template <int W, int F, int DC = 0, unsigned MASKC = 0, int VIEWC = 0>
+// SAVE = 2: the training forward of DN_PREC_BF16_S8 - the same chain also streams every stage's output (and both encodings) as
+// e4m3 units in the s8-48 layout and the ReLU mask words (mlp_geo48.h) to HBM: non-temporal scalar-base 16-byte stores
+// (mlp_device.h store16_uniform), a unit every fourth output tile per point group.
+template <int W, int F, int DC = 0, unsigned MASKC = 0, int VIEWC = 0, int SAVE = 0>
 __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdParams p, G48Params q) {
+  static_assert(SAVE == 0 || (SAVE == 2 && F == 1), "saved tensors: the 8-bit layout, bf16 arithmetic");
   constexpr bool FIXED = DC > 0;
   constexpr bool ST = !FIXED;   // settle at stage ends
+  constexpr bool CL = SAVE != 0;   // clamp stage outputs to e4m3's range (emit48)
 #if defined(DN_PIPE_ASM_READS) && defined(DN_PIPE_LEADER_DMA) && !defined(DN_G48_BARRIER_EVERY_PHASE)
   // barrier period in pieces: every second phase where a phase's parity is a compile-time position - the fixed-shape W = 256
-  // instance (every stage boundary of D8 / skip 4 falls on an even phase, 74 phases per pass) - every phase elsewhere
-  constexpr int PH = (FIXED && W == 256) ? 2 * kPhasePieces : kPhasePieces;
+  // instance (every stage boundary of D8 / skip 4 falls on an even phase, 74 phases per pass) - every phase elsewhere.
+  // (The two-phase form waits with vmcnt(0): with the training forward's stores in the queue that wait would be for HBM.)
+  constexpr int PH = (FIXED && W == 256 && SAVE == 0) ? 2 * kPhasePieces : kPhasePieces;
 #else
   constexpr int PH = kPhasePieces;
 #endif
@@ -313,6 +162,19 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
   int vset = 0;  // which view-direction rows hold this tile's directions (wave-uniform, flips every tile)
   const int n_tiles = static_cast<int>(p.n_tiles);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, vset ^= 1) {
+    // training forward: this wave's three point groups' saved-unit bases and its mask words' (s8-48 layout, mlp_geo48.h) - wave-
+    // uniform, kept in scalar registers for the tile; every store adds a small offset (store16_uniform_at)
+    const char* act_grp[PT] = {nullptr, nullptr, nullptr};
+    const char* mask_base = nullptr;
+    if constexpr (SAVE != 0) {
+      const long long wt = static_cast<long long>(tile) * WAVES + wave;
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        const long long G = wt * PT + t;   // the group's index along the point sequence
+        act_grp[t] = uniform_ptr(p.act + ((G >> 1) * p.act_pieces * 2 + (G & 1)) * kPieceBytes);
+      }
+      mask_base = uniform_ptr(p.masks + wt * p.mask_words * (2 * kPieceBytes));
+    }
     // ---- xyz encoding of this lane's three points, its 16 columns each, into the per-wave LDS stash ----
     {
       const int ln = fresh_lane();
@@ -342,17 +204,91 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
           x[c] = (p.mode == 0) ? in[t][c] + in[t][3 + c] * in[t][6] : in[t][c];
         float xr[3];
         rotate3(x, ln >> 4, xr);
+        BP8 pk[KXP];
 #pragma unroll
         for (int k = 0; k < KXP; ++k) {
           BP8 piece;
 #pragma unroll
           for (int e = 0; e < 8; ++e) piece[e] = static_cast<Elem>(pe_value(xr[(k * 8 + e) % 3], tabx[k * 8 + e]));
           *reinterpret_cast<BP8*>(pex + (t * KXP + k) * kPieceBytes) = piece;
+          pk[k] = piece;
+        }
+        if constexpr (SAVE != 0) {
+          static_assert(KXP == 2, "the xyz panel is one saved unit");
+          // (the helper lambdas of the tile body are defined further down: the same store, spelled out)
+          typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+          typedef short s16x2_ __attribute__((ext_vector_type(2)));
+          typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+          auto cv = [](unsigned d0, unsigned d1) {
+            s16x2_ r = {0, 0};
+            r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, __builtin_bit_cast(bf16x2_, d0), 1.0f, false);
+            r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, __builtin_bit_cast(bf16x2_, d1), 1.0f, true);
+            return __builtin_bit_cast(unsigned, r);
+          };
+          const u32x4_ a = __builtin_bit_cast(u32x4_, pk[0]), b = __builtin_bit_cast(u32x4_, pk[1]);
+          store16_uniform_at(act_grp[t], static_cast<unsigned>(p.slot_xyz) * (2 * kPieceBytes), static_cast<unsigned>(ln) * 16u,
+                             make_uint4(cv(a[0], a[1]), cv(a[2], a[3]), cv(b[0], b[1]), cv(b[2], b[3])));
         }
       }
     }
     auto pe_xyz = [&](int t, int k) { return *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + (t * KXP + k) * kPieceBytes); };
     auto no_pe = [&](int, int) { return BP8{}; };
+    // ---- training forward: saved units and mask words (s8-48 layout, mlp_geo48.h) ----
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned maskw[PT][2];
+    auto mask_clear = [&]() {
+#pragma unroll
+      for (int t = 0; t < PT; ++t) { maskw[t][0] = 0u; maskw[t][1] = 0u; }
+    };
+    // two 16-bit pairs -> four e4m3 bytes
+    auto to_e4m3 = [](unsigned d0, unsigned d1) {
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      s16x2 r = {0, 0};
+      r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, __builtin_bit_cast(bf16x2, d0), 1.0f, false);
+      r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, __builtin_bit_cast(bf16x2, d1), 1.0f, true);
+      return __builtin_bit_cast(unsigned, r);
+    };
+    auto save_unit = [&](auto t_c, int slot, const BP8& lo, const BP8& hi) {
+      if constexpr (SAVE != 0) {
+        constexpr int t = decltype(t_c)::value;
+        const u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
+        store16_uniform_at(act_grp[t], static_cast<unsigned>(slot) * (2 * kPieceBytes), pipe.lane16,
+                           make_uint4(to_e4m3(a[0], a[1]), to_e4m3(a[2], a[3]), to_e4m3(b[0], b[1]), to_e4m3(b[2], b[3])));
+      }
+    };
+    // after emit48 of output tile nt of group t into bo: ReLU mask bits off the packed outputs, and every fourth tile one unit
+    auto mask_tail = [&](auto nt_c, auto t_c, const auto& bo) {
+      if constexpr (SAVE != 0) {
+        constexpr int nt = decltype(nt_c)::value, t = decltype(t_c)::value;
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        const u16x2 one = {1, 1};
+        const u32x4 w = __builtin_bit_cast(u32x4, bo[nt / 2]);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          // (through a named scalar: __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index - hipcc 7.2)
+          const unsigned pair = w[(nt & 1) * 2 + d];
+          const unsigned m = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, pair), one));
+          // (opaque: as plain ORs the optimiser may reassociate the stage's chain and keep every m alive to its end)
+          unsigned mw = maskw[t][nt >> 3];   // (asm operands do not capture: name a local)
+          asm volatile("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(mw) : "v"(m), "n"((nt & 7) * 2 + d));
+          maskw[t][nt >> 3] = mw;
+        }
+      }
+    };
+    auto unit_tail = [&](auto nt_c, auto t_c, const auto& bo, int slot0) {
+      if constexpr (SAVE != 0) {
+        constexpr int nt = decltype(nt_c)::value;
+        if constexpr (nt % 4 == 3) save_unit(t_c, slot0 + nt / 4, bo[nt / 2 - 1], bo[nt / 2]);
+      }
+    };
+    auto mask_store = [&](int stage) {
+      if constexpr (SAVE != 0) {
+        store16_uniform_at(mask_base, static_cast<unsigned>(stage) * (2 * kPieceBytes), pipe.lane16, make_uint4(maskw[0][0], maskw[0][1], maskw[1][0], maskw[1][1]));
+        store16_uniform_at(mask_base, static_cast<unsigned>(stage) * (2 * kPieceBytes) + kPieceBytes, pipe.lane16, make_uint4(maskw[2][0], maskw[2][1], 0u, 0u));
+      }
+    };
+    constexpr int KHU = KH / 2;   // units of a hidden vector
 
     BP8 ba[PT][KH], bb[PT][KH];
     int bias_tile = 0;
@@ -367,7 +303,8 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 #pragma unroll
         for (int k = 0; k < KXP; ++k) pe[t][k] = pe_xyz(t, k);
       run_stage48<F, NT, KXP, 0, 0, false, ST, 0, PH>(pipe, pe, no_pe, bias_at(0), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
-        emit48<F, false, decltype(nt_c)::value>(acc, ba[decltype(t_c)::value]);
+        emit48<F, false, decltype(nt_c)::value, CL>(acc, ba[decltype(t_c)::value]);
+        unit_tail(nt_c, t_c, ba[decltype(t_c)::value], p.slot_layer1);
       });
     }
     bias_tile += NT;
@@ -382,9 +319,13 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         run_stage48<F, 1, KH, 0, 0, false, ST, 0, PH>(pipe, hx, no_pe, bias_at(bias_tile), 0u, [&](auto, auto t_c, const f32x4& acc) {
           out4[decltype(t_c)::value][3] = acc[0];  // row 0 lives in lane group 0, register 0
         });
+        mask_clear();
         run_stage48<F, NT, KH, 0, KH % PH, false, ST, 0, PH, 1>(pipe, hx, no_pe, bias_at(bias_tile + 1), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
-          emit48<F, true, decltype(nt_c)::value>(acc, hy[decltype(t_c)::value]);
+          emit48<F, true, decltype(nt_c)::value, CL>(acc, hy[decltype(t_c)::value]);
+          mask_tail(nt_c, t_c, hy[decltype(t_c)::value]);
+          unit_tail(nt_c, t_c, hy[decltype(t_c)::value], p.slot_feat);
         }, &trk);
+        mask_store(p.D - 1);
         bias_tile += NT + 1;
         // ---- view-direction encoding (one 32-deep piece per point group) ----
         // fenced on both sides: interleaved into the fc_feat MFMAs its temporaries push finished activation pieces to scratch
@@ -407,6 +348,15 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 #pragma unroll
             for (int e = 0; e < 8; ++e) piece[e] = static_cast<Elem>(pe_value(vr[e % 3], tabd[e]));
             *reinterpret_cast<BP8*>(pex + t * kPieceBytes) = piece;
+            if constexpr (SAVE != 0) {
+              // one piece = 8 bytes per lane: lanes of groups 0 / 1 store [their own 8 bytes | those of groups 2 / 3] (the upper
+              // half of the unit's rows is then a copy nobody reads) - one 32-feature fragment for the weight-gradient kernel
+              const u32x4 a = __builtin_bit_cast(u32x4, piece);
+              const unsigned w0 = to_e4m3(a[0], a[1]), w1 = to_e4m3(a[2], a[3]);
+              const auto s0 = __builtin_amdgcn_permlane32_swap(w0, w0, false, false);   // [1]: lanes < 32 receive lane + 32's word
+              const auto s1 = __builtin_amdgcn_permlane32_swap(w1, w1, false, false);
+              store16_uniform_at(act_grp[t], static_cast<unsigned>(p.slot_dir) * (2 * kPieceBytes), static_cast<unsigned>(ln) * 16u, make_uint4(w0, w1, s0[1], s1[1]));
+            }
             __builtin_amdgcn_sched_barrier(0);
           });
         }
@@ -418,9 +368,13 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 #pragma unroll
         for (int t = 0; t < PT; ++t) ped[t] = *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes);
         auto pe_dir = [&](int t, int) { return ped[t]; };
+        mask_clear();
         run_stage48<F, NT / 2, KH, KDP, POS_D, false, ST, 0, PH, 1>(pipe, hy, pe_dir, bias_at(bias_tile), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
-          emit48<F, true, decltype(nt_c)::value>(acc, bg[decltype(t_c)::value]);
+          emit48<F, true, decltype(nt_c)::value, CL>(acc, bg[decltype(t_c)::value]);
+          mask_tail(nt_c, t_c, bg[decltype(t_c)::value]);
+          unit_tail(nt_c, t_c, bg[decltype(t_c)::value], p.slot_dirout);
         }, &trk);
+        mask_store(p.D);
         bias_tile += NT / 2;
         // ---- fc_rgb (models.py:253) ----
         constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % PH;
@@ -453,7 +407,12 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         constexpr int i = decltype(i_c)::value;
         auto& bin = (i % 2 == 0) ? ba : bb;
         auto& bout = (i % 2 == 0) ? bb : ba;
-        auto emit = [&](auto nt_c, auto t_c, const f32x4& acc) { emit48<F, true, decltype(nt_c)::value>(acc, bout[decltype(t_c)::value]); };
+        auto emit = [&](auto nt_c, auto t_c, const f32x4& acc) {
+          emit48<F, true, decltype(nt_c)::value, CL>(acc, bout[decltype(t_c)::value]);
+          mask_tail(nt_c, t_c, bout[decltype(t_c)::value]);
+          unit_tail(nt_c, t_c, bout[decltype(t_c)::value], p.slot_trunk0 + i * KHU);
+        };
+        mask_clear();
         if constexpr ((MASKC >> i) & 1u) {
 #ifdef DN_G48_SKIP_PE_FROM_LDS
           run_stage48<F, NT, KH, KXP, 0, false, false, 0, PH>(pipe, bin, pe_xyz, bias_at(bias_tile), 0u, emit);
@@ -468,6 +427,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         } else {
           run_stage48<F, NT, KH, 0, 0, false, false, 0, PH, (i == 0 ? 2 : 1)>(pipe, bin, no_pe, bias_at(bias_tile), 0u, emit, &trk);
         }
+        mask_store(i);
         bias_tile += NT;
       });
 #if defined(DN_STAMP) && DN_STAMP == 4
@@ -479,13 +439,17 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       // two layers per iteration of a run-time loop
       auto trunk_layer = [&](int i, const BP8 (&bin)[PT][KH], BP8 (&bout)[PT][KH]) __attribute__((always_inline)) {
         auto emit = [&](auto nt_c, auto t_c, const f32x4& acc) {
-          emit48<F, true, decltype(nt_c)::value>(acc, bout[decltype(t_c)::value]);
+          emit48<F, true, decltype(nt_c)::value, CL>(acc, bout[decltype(t_c)::value]);
+          mask_tail(nt_c, t_c, bout[decltype(t_c)::value]);
+          unit_tail(nt_c, t_c, bout[decltype(t_c)::value], p.slot_trunk0 + i * KHU);
         };
+        mask_clear();
         // (the range tracker costs the run-time-shape W = 256 instance 315 spilled registers: it tracks in the heads only, and
         // dn_fp16_range_guard() says so)
         constexpr int TRK_RT = W == 128 ? 2 : 0;
         if ((p.skip_mask >> i) & 1u) run_stage48<F, NT, KH, KXP, 0, false, true, 0, kPhasePieces, TRK_RT>(pipe, bin, pe_xyz, bias_at(bias_tile), 0u, emit, &trk);
         else run_stage48<F, NT, KH, 0, 0, false, true, 0, kPhasePieces, TRK_RT>(pipe, bin, no_pe, bias_at(bias_tile), 0u, emit, &trk);
+        mask_store(i);
         bias_tile += NT;
       };
       int i = 0;
@@ -692,6 +656,12 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
   const bool paper = d.hidden_size == 256 && d.num_layers == 8 && L.skip_mask == 0x10u && d.use_viewdirs;
   const bool shipped = d.hidden_size == 128 && d.num_layers == 4 && L.skip_mask == 0u && d.use_viewdirs;
   const bool fixed_ok = std::getenv("DEXNERF_G48_RUNTIME_SHAPE") == nullptr;
+  if (p.act != nullptr) {   // training forward (DN_PREC_BF16_S8): saved units + mask words
+    if (precision != DN_PREC_BF16 || !p.save8) { set_error("mlp_forward48(train): the 48-point training forward is the bf16 / 8-bit-saved-tensor mode"); return DN_E_UNSUPPORTED; }
+    if (paper && fixed_ok) return launch(mlp_forward48_kernel<256, 1, 8, 0x10u, 1, 2>);
+    if (shipped && fixed_ok) return launch(mlp_forward48_kernel<128, 1, 4, 0u, 1, 2>);
+    return d.hidden_size == 256 ? launch(mlp_forward48_kernel<256, 1, 0, 0u, 0, 2>) : launch(mlp_forward48_kernel<128, 1, 0, 0u, 0, 2>);
+  }
   if (precision == DN_PREC_F16) {
     if (paper && fixed_ok) return launch(mlp_forward48_kernel<256, 2, 8, 0x10u, 1>);
     if (shipped && fixed_ok) return launch(mlp_forward48_kernel<128, 2, 4, 0u, 1>);
@@ -703,3 +673,4 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
 }
 
 }  // namespace dn
+

@@ -115,7 +115,105 @@ inline size_t g48_region_bytes(const dn_mlp_desc& d) {
 }
 
 bool g48_range_guard_complete(const dn_mlp_desc& d);
+// ---- training in the 48-point geometry: the 8-bit saved tensors of DN_PREC_BF16_S8 ("s8-48" layout) ------------------------
+// A wave's 48 points are three 16-point groups; groups are numbered along the point sequence (group G = point / 16) and two
+// consecutive groups form one 32-point record T = G / 2 - the unit of the weight-gradient kernel's K = 64 contraction.
+// Saved unit (1 KiB = 64 lanes x 16 bytes) of group G, slot s: lane (g = lane / 16, j = lane % 16) holds, for point j of the
+// group, the 8 + 8 bytes of B pieces 2s and 2s + 1 of the saved vector (byte b: piece 2s + b / 8, element b % 8 - feature
+// g48_hidden_col(piece, g, element) of a hidden vector, slot g48_pe_col of an encoding panel).  Address of a unit:
+//   buffer + ((T * units_per_group + s) * 2 + (G & 1)) * 1 KiB
+// so that, seen from the weight-gradient kernel, a record is a run of 2 * units_per_group 1-KiB units and the two groups'
+// units of one slot sit side by side.  Buffers are sized for whole workgroup tiles (384 points = 12 records).
+// ReLU masks: per wave tile (48 points) and masked stage two 1-KiB words, lane = 16 bytes:
+//   word 0 = [group 0: lo, hi | group 1: lo, hi], word 1 = [group 2: lo, hi | 0, 0]; bit of accumulator register r of 16-row
+//   tile nt: dword nt / 8, bit ((nt % 8) * 2 + r / 2) + 16 * (r % 2) - i.e. straight from the packed 16-bit ReLU outputs
+//   (v_pk_min_u16(pair, 1) << position) and back onto packed pairs in the backward (((w >> position) & 0x00010001) * 0xFFFF).
+struct TrainLayout48 {
+  int32_t kh_u;                     // units of a W-wide hidden vector
+  int32_t act_units;                // saved forward units per 16-point group
+  int32_t slot_xyz, slot_dir, slot_layer1, slot_trunk0, slot_feat, slot_dirout;
+  int32_t mask_stages;              // masked stages: (D-1) trunk + feat + dirout
+  int32_t grad_units;               // saved dL/d(pre-activation) units per group
+  int32_t gslot_dirout, gslot_feat, gslot_trunk0, gslot_layer1;   // gslot_trunk0 + i * kh_u for layers_xyz[i]
+  int32_t gslot_out;                // custom unit [d rgb piece | d alpha piece] (viewdirs) or [d out piece | 0]
+};
+
+inline void build_train_layout48(const dn_mlp_desc& d, TrainLayout48* t) {
+  const int W = d.hidden_size, D = d.num_layers;
+  t->kh_u = W / 64;
+  int s = 0;
+  t->slot_xyz = s; s += 1;                                   // 64-wide xyz panel = two 32-deep pieces
+  t->slot_dir = s; s += d.use_viewdirs ? 1 : 0;              // one piece: lanes g < 2 carry [own 8 bytes | the 8 bytes of g + 2]
+  t->slot_layer1 = s; s += t->kh_u;
+  t->slot_trunk0 = s; s += (D - 1) * t->kh_u;
+  t->slot_feat = s; s += d.use_viewdirs ? t->kh_u : 0;
+  t->slot_dirout = s; s += d.use_viewdirs ? W / 128 : 0;
+  t->act_units = s;
+  t->mask_stages = (D - 1) + (d.use_viewdirs ? 2 : 0);
+  int g = 0;
+  t->gslot_dirout = g; g += d.use_viewdirs ? W / 128 : 0;
+  t->gslot_feat = g; g += d.use_viewdirs ? t->kh_u : 0;
+  t->gslot_trunk0 = g; g += (D - 1) * t->kh_u;
+  t->gslot_layer1 = g; g += t->kh_u;
+  t->gslot_out = g; g += 1;
+  t->grad_units = g;
+}
+
+// 32-point records the buffers of an n_points launch hold (whole 384-point workgroup tiles)
+inline long long g48_padded_records(long long n_points) {
+  return (n_points + kG48PointsPerWg - 1) / kG48PointsPerWg * (kG48PointsPerWg / 32);
+}
+
+// Which networks train in the 48-point geometry (DN_PREC_BF16_S8): W = 128 needs whole 64-feature units for layers_dir.0's
+// 64 outputs (it has them), both widths need L_xyz = 10 panels like the other training kernels
+inline bool g48_train_supported(const dn_mlp_desc& d) {
+  return g48_supported(d, DN_PREC_BF16) && d.num_encoding_fn_xyz == 10;
+}
+
+// Backward-data stream of the 48-point chain: 16-row tiles of the TRANSPOSED weights, 32-deep pieces whose k order is the
+// forward layer's output features in accumulator order (g48_hidden_col), plus one optional custom piece (k = 8 g + e:
+// d rgb / d alpha / d out rows).  Stages in consumption order, as build_backward_layout (mlp_layout.h).  No bias tiles.
+inline int build_backward_layout48(const dn_mlp_desc& d, NetLayout* out) {
+  const int W = d.hidden_size, D = d.num_layers;
+  const int DX = 3 + 6 * d.num_encoding_fn_xyz, DD = 3 + 6 * d.num_encoding_fn_dir;
+  NetLayout& L = *out;
+  L = NetLayout{};
+  L.W = W; L.LX = d.num_encoding_fn_xyz; L.LD = d.num_encoding_fn_dir; L.D = D; L.use_viewdirs = d.use_viewdirs;
+  int piece = 0, s = 0;
+  auto add = [&](int n_rows, int k_hidden, int custom, int src, int src2, int ld) {
+    StageDesc& t = L.st[s++];
+    t = StageDesc{};
+    t.n_tiles = n_rows / 16; t.hidden_in = k_hidden; t.src = src; t.src2 = src2;
+    t.n_real = n_rows; t.ld = ld; t.first_tile2 = -1; t.transposed = 1; t.custom_k = custom;
+    t.pieces_per_tile = k_hidden / 32 + (custom > 0 ? 1 : 0);
+    t.piece0 = piece;
+    piece += t.n_tiles * t.pieces_per_tile;
+  };
+  for (int i = 0; i < D - 1; ++i)
+    if ((i % d.skip_connect_every == 0) && i > 0 && i != D - 1) L.skip_mask |= (1u << i);
+  if (d.use_viewdirs) {
+    const int i_dir = D, i_alpha = D + 1, i_rgb = D + 2, i_feat = D + 3;
+    add(W / 2, 0, 3, i_rgb, -1, W / 2);              // d g    = fc_rgb^T d rgb
+    add(W, W / 2, 0, i_dir, -1, W + DD);             // d feat = layers_dir.0[:, :W]^T d dirpre
+    add(W, W, 1, i_feat, i_alpha, W);                // d h    = fc_feat^T d featpre + fc_alpha^T d alpha
+  } else {
+    add(W, 0, 4, D, -1, W);                          // d h    = fc_out^T d out
+  }
+  for (int i = D - 2; i >= 0; --i) {
+    const bool wide = (L.skip_mask >> i) & 1u;
+    add(W, W, 0, 1 + i, -1, wide ? W + DX : W);      // d x_i  = layers_xyz[i][:, :W]^T d pre_i
+  }
+  L.n_stages = s;
+  L.total_pieces = round_up(piece, kPhasePieces);
+  return 0;
+}
+
 int launch_pack48(const dn_mlp_desc& d, int precision, const PackPtrs& ptrs, char* region, hipStream_t stream);
 int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p, const char* region, hipStream_t stream);
+int backward48_entry(const dn_mlp_desc* desc, const void* packed_bwd, const float* g_out, const void* masks, int64_t n_points,
+                     void* grads, float grad_scale, hipStream_t stream);                                  // mlp_train48.hip
+int unpack48_entry(const dn_mlp_desc* desc, int which, const void* native, int64_t n_points, int slot, int width, int kind, float* out,
+                   int ld_out, int col0, float grad_scale, hipStream_t stream);                             // mlp_train48.hip
+int launch_pack48_backward(const dn_mlp_desc& d, const PackPtrs& ptrs, char* packed, hipStream_t stream);   // mlp_train48.hip
 
 }  // namespace dn

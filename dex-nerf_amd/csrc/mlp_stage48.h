@@ -1,0 +1,176 @@
+// Shared by the 48-points-per-wave kernels (mlp_fused48.hip: inference + training forward; mlp_train48.hip: backward-data chain):
+// the Pipe configuration of this geometry and the per-stage MFMA loop.  Included by those two translation units only.
+#pragma once
+#if defined(DN_PREFETCH) && !defined(DN_ABLATION_BUILD)
+#error "DN_PREFETCH is set by this file (the 48-point kernel's FIFO depth); a command-line value is an ablation hook (scripts/build_exp.sh)"
+#endif
+#ifdef DN_G48_PREFETCH   // (ablation hook, refused by mlp_device.h outside an ablation build)
+#define DN_PREFETCH DN_G48_PREFETCH
+#else
+#define DN_PREFETCH 2
+#endif
+#define DN_PREFETCH_SET_BY_KERNEL_SOURCE 1
+#define DN_PIPE_SCALAR_STATE 1   // ring bookkeeping in SGPRs: frees the VGPRs that were spilling (0.5 % on the launch)
+#ifndef DN_G48_COMPILER_READS    // (ablation hook: the r01 pipeline with compiler-issued reads and waits)
+#define DN_PIPE_ASM_READS 1      // A-fragment / bias LDS reads and their counted waits as opaque asm (mlp_device.h Pipe)
+#endif
+#ifndef DN_G48_SYMMETRIC_DMA     // (ablation hook: every wave fetches two pieces per phase, as in round 1)
+// Asymmetric roles.  The two waves of a SIMD do not share the matrix pipe fairly: the older one (waves 0-3) wins the
+// arbitration, runs a phase ahead and then sits at the phase barrier (s_memtime stamps, profiles/r02_fine_net_stalls.md:
+// ~640 cycles per phase against ~160 for waves 4-7), while the younger one - the critical path - also paid ~300 cycles per
+// phase of its own LDS-DMA issue.  So the waves with the slack fetch the whole weight stream (four pieces each) and
+// waves 4-7 issue MFMAs only.
+#define DN_PIPE_LEADER_DMA 1
+#endif
+#include "mlp_geo48.h"
+
+namespace dn {
+
+// F = 1: bf16, 2: fp16 (Prec<F> of mlp_device.h): same MFMA rate and layouts
+template <int F>
+__device__ __forceinline__ f32x4 mfma48(typename Prec<F>::BPiece a, typename Prec<F>::BPiece b, f32x4 c) {
+  if constexpr (F == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// how many of the pieces [q0, q1) of the stream are ever fetched: all, except - behind the LAST stage of a pass, which ends at
+// position END - the PAD padding pieces nobody consumes
+template <bool LAST, int END, int PAD>
+constexpr int g48_issued(int q0, int q1) {
+  int n = 0;
+  for (int q = q0; q < q1; ++q) n += (LAST && q >= END && q < END + PAD) ? 0 : 1;
+  return n;
+}
+
+// One GEMM stage: NT_OUT 16-row output tiles, KH hidden pieces + KP encoding pieces per tile, three point groups.
+// bias_addr: LDS byte address of this lane group's 16 bytes of the stage's bias tile 0; the bias tiles of a tile pass are
+// contiguous in stream order, so "the next tile's bias" is the next 64 bytes, except after the last stage of the pass
+// (LAST): there it is next_addr (tile 0 of layer1).  Read pipeline (DN_PIPE_ASM_READS): step k of a tile = take A(p),
+// three MFMAs, read A(p+2); the next tile's bias read goes out right after the A read of step KT-2, i.e. between A(next
+// tile, 0) and A(next tile, 1) - so with a FIFO of P pieces the wait counts are P - 1 everywhere and P at k = KT-1; the
+// bias take at k = 0 waits with 1 (one A read was issued after the bias read), which also lands every older A read.
+// TRK (fp16 range guard, FwdParams::range_flag): 1 / 2 = fold the bit patterns of this stage's hidden INPUT pieces `bh` into the
+// running unsigned 16-bit maximum `*trk` (2: the input carries no ReLU, clear the sign bits first) - a few v_pk_max_u16 per output
+// tile, on registers that are live for the whole stage anyway (tracking the freshly converted outputs instead kept them live
+// behind a serial chain: 776 spilled registers).  A final pattern >= 0x7C00 is an infinity or a NaN.
+// BIAS = false (the backward-data chain): no bias rows - the accumulators start at zero and no bias read rides in the pipeline.
+template <int F, int NT_OUT, int KH, int KP, int POS0, bool LAST = false, bool SETTLE = true, int PAD = 0, int PH = kPhasePieces, int TRK = 0,
+          bool BIAS = true, class PipeT, class BH, class BP, class Emit>
+__device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, unsigned bias_addr, unsigned next_addr, Emit&& emit,
+                                            unsigned* trk = nullptr) {
+  constexpr int PT = 3, KT = KH + KP;
+  static_assert(KT >= 2 || !BIAS, "the bias prefetch distance assumes at least two pieces per tile");
+  static_for<NT_OUT>([&](auto nt_c) {
+    constexpr int nt = decltype(nt_c)::value;
+    f32x4 acc[PT];
+    static_for<KT>([&](auto k_c) {
+      constexpr int k = decltype(k_c)::value;
+      constexpr int pos = POS0 + nt * KT + k;
+#if defined(DN_STAMP) && DN_STAMP == 1
+      if constexpr (pos % 4 == 0 && pos % kPhasePieces != 0) pipe.template substamp<(pos % kPhasePieces) / 4>();
+#endif
+      pipe.template at_position<PH, pos>();   // phase boundary (barrier + weight DMA) / mid-phase DMA, if this is one
+#ifdef DN_PIPE_ASM_READS
+      if constexpr (k == 0) {
+        f32x4 b = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (BIAS) b = pipe.template bias_take<1>();   // issued before A(pos + 1): one younger read may stay in flight
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[t] = b;
+      }
+      // younger reads of ours than A(pos): the other FIFO entries - those that were issued at all (see PAD below) - plus
+      // the next tile's bias at k = KT - 1
+      constexpr int newer = g48_issued<LAST, POS0 + NT_OUT * KT, PAD>(pos + 1, pos + kPrefetch) + ((BIAS && k == KT - 1) ? 1 : 0);
+      const auto a = __builtin_bit_cast(typename Prec<F>::BPiece, pipe.template take<pos, newer>());
+#else
+      if constexpr (k == 0) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(pipe.ring + (bias_addr - pipe.ring_addr) + nt * 64);
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[t] = b;
+      }
+      const auto a = __builtin_bit_cast(typename Prec<F>::BPiece, pipe.af[pos % kPrefetch]);
+#endif
+      static_for<PT>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        if constexpr (k < KH) acc[t] = mfma48<F>(a, bh[t][k], acc[t]);
+        else acc[t] = mfma48<F>(a, bp(t, k - KH), acc[t]);
+      });
+#ifdef DN_PIPE_ASM_READS
+      // PAD padding pieces follow the last stage of a pass (Pipe::skip): a read of one of THOSE would never be consumed, and
+      // a fragment nobody consumes is a dead value to the compiler - it reuses the registers while the read is in flight
+      if constexpr (g48_issued<LAST, POS0 + NT_OUT * KT, PAD>(pos + kPrefetch, pos + kPrefetch + 1) == 1) pipe.template prefetch<pos>();
+#else
+      pipe.template prefetch<pos>();
+#endif
+#ifdef DN_PIPE_ASM_READS
+      if constexpr (BIAS && k == KT - 2) {
+        if constexpr (nt + 1 < NT_OUT) pipe.template bias_prefetch<(nt + 1) * 64>(bias_addr);
+        else if constexpr (LAST) pipe.template bias_prefetch<0>(next_addr);
+        else pipe.template bias_prefetch<NT_OUT * 64>(bias_addr);
+      }
+#else
+      __builtin_amdgcn_sched_group_barrier(0x008, PT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#endif
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<PT>([&](auto t_c) { emit(nt_c, t_c, acc[decltype(t_c)::value]); });
+    if constexpr (F == 2 && TRK != 0) {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      constexpr int TOT = PT * KH * 4;   // input dwords of this wave
+      constexpr int Q0 = nt * TOT / NT_OUT, Q1 = (nt + 1) * TOT / NT_OUT;
+      static_for<Q1 - Q0>([&](auto q_c) {
+        constexpr int q = Q0 + decltype(q_c)::value;
+        const unsigned v = __builtin_bit_cast(u32x4, bh[q / (KH * 4)][(q / 4) % KH])[q % 4];
+        // opaque: written as plain max operations the optimiser reassociates the whole kernel's chain into one expression
+        // evaluated at the end of the tile loop - every stage's pieces stay live until then (hundreds of spilled registers)
+        unsigned t = *trk;
+        if constexpr (TRK == 2) {
+          unsigned tmp;
+          asm volatile("v_and_b32 %1, 0x7fff7fff, %2\n\tv_pk_max_u16 %0, %0, %1" : "+v"(t), "=&v"(tmp) : "v"(v));
+        } else {
+          asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(t) : "v"(v));
+        }
+        *trk = t;
+      });
+    }
+  });
+#ifdef DN_PIPE_ASM_READS
+  // run-time network shape: no read stays in flight across a stage boundary (control flow merges there: see Pipe::settle);
+  // the fixed-shape instances are straight-line code from the top of a tile pass to its end and settle once, there
+  if constexpr (SETTLE) pipe.template settle<BIAS>();
+#endif
+}
+
+// rows 4g..4g+3 of output tile NT -> elements (NT & 1) * 4 .. + 3 of B piece NT / 2 (g48_hidden_col)
+// CLAMP (training forward with 8-bit saved tensors): the stage output is limited to e4m3's range (448) before it is rounded
+// to 16 bits, so that the saved byte can be formed straight from the 16-bit pairs (v_cvt_scalef32_pk_fp8_bf16 does not
+// saturate: an overflow converts to NaN - measured, scripts/micro/cvt_scale_probe.hip).  No activation of a trainable net is
+// anywhere near 448: below it the bits are the inference kernel's.
+template <int F, bool RELU, int NT, bool CLAMP = false, class BO>
+__device__ __forceinline__ void emit48(const f32x4& acc, BO& bo) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef typename Prec<F>::Elem e16x2 __attribute__((ext_vector_type(2)));
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w = __builtin_bit_cast(u32x4, bo[NT / 2]);
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    f32x2 f = {acc[2 * d], acc[2 * d + 1]};
+    if constexpr (CLAMP) {
+      if constexpr (RELU) { f[0] = fminf(f[0], kE4m3Max); f[1] = fminf(f[1], kE4m3Max); }
+      else { f[0] = __builtin_amdgcn_fmed3f(f[0], -kE4m3Max, kE4m3Max); f[1] = __builtin_amdgcn_fmed3f(f[1], -kE4m3Max, kE4m3Max); }
+    }
+    e16x2 v = __builtin_convertvector(f, e16x2);  // one packed convert
+    if constexpr (RELU) {  // a negative bf16 / fp16 is a negative int16 (mlp_device.h make_piece)
+      s16x2 bits = __builtin_bit_cast(s16x2, v);
+      const s16x2 zero = {0, 0};
+      bits = __builtin_elementwise_max(bits, zero);
+      v = __builtin_bit_cast(e16x2, bits);
+    }
+    w[(NT & 1) * 2 + d] = __builtin_bit_cast(unsigned, v);
+  }
+  bo[NT / 2] = __builtin_bit_cast(typename Prec<F>::BPiece, w);
+}
+
+}  // namespace dn
+

@@ -10,6 +10,7 @@
 // the end of this file (bf16 MFMA, or exact-fp32 MFMA in the parity mode).
 // In practice bound by the HBM write stream of the stored gradients (3.6 KiB/point at D8/W256), not by the MFMAs.
 #include "mlp_internal.h"
+#include "mlp_geo48.h"
 #include <atomic>
 #include <vector>
 #include <cmath>
@@ -38,23 +39,6 @@ struct BwdParams {
 static std::atomic<float> g_s8_grad_scale{65536.0f};
 
 constexpr int kBwdWaveLds = 6 * kPieceBytes;  // per wave: 2 output-gradient slots + 4 mask-word slots (1 KiB each)
-
-// 16 B per lane, per-lane global address -> LDS (M0 base + lane*16), as an opaque instruction: the counted waits of
-// the weight pipeline cover it (it is issued >= 3 phases before its data is read) and hipcc never waits on it.
-__device__ __forceinline__ void dma16_lanes(const void* src_lane, unsigned lds_addr) {
-  const unsigned lds = __builtin_amdgcn_readfirstlane(lds_addr);
-  const void* src = src_lane;
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %[keep], m0\n\t"
-      "s_mov_b32 m0, %[lds]\n\t"
-      "s_nop 1\n\t"
-      "global_load_lds_dwordx4 %[vaddr], off\n\t"
-      "s_mov_b32 m0, %[keep]"
-      : [keep] "=&s"(keep)
-      : [lds] "s"(lds), [vaddr] "v"(src)
-      : "memory");
-}
 
 template <int W, int BF16, bool S8 = false>   // S8: the saved gradients at 8 bits (e5m2 x grad_scale), two pieces per 1 KiB unit
 __global__ __launch_bounds__((waves_of<BF16, 1>() * 64), (BF16 ? 2 : 1)) void mlp_backward_kernel(BwdParams p) {
@@ -328,16 +312,35 @@ extern "C" int dn_mlp_train_sizes(const dn_mlp_desc* desc, int precision, int64_
   DN_REQUIRE(precision != DN_PREC_F16, "training kernels exist for fp32 and bf16 (fp16 is a render-only mode)");
   DN_REQUIRE(n_points >= 0 && act_bytes && mask_bytes && grad_bytes, "dn_mlp_train_sizes: bad arguments");
   DN_REQUIRE(desc->num_encoding_fn_xyz == 10, "dn_mlp_train_sizes: training kernels are built for L_xyz = 10");
+  if (s8) {   // s8-48 layout (mlp_geo48.h): units per 16-point group, two groups per 32-point record, whole 384-point tiles
+    if (!g48_train_supported(*desc)) {
+      set_error("dn_mlp_train_sizes: the 8-bit-saved-tensor training kernels run the 48-point geometry (W in {128, 256}, L_xyz = 10, a depth whose bias rows fit its LDS); train this network with DN_PREC_BF16");
+      return DN_E_UNSUPPORTED;
+    }
+    TrainLayout48 t8;
+    build_train_layout48(*desc, &t8);
+    const size_t records = static_cast<size_t>(g48_padded_records(n_points));
+    *act_bytes = records * 2 * t8.act_units * kPieceBytes;
+    *mask_bytes = records / (kG48PointsPerWg / 32) * kG48Waves * t8.mask_stages * 2 * kPieceBytes;
+    *grad_bytes = records * 2 * t8.grad_units * kPieceBytes;
+    return 0;
+  }
   TrainLayout t;
   build_train_layout(*desc, precision, &t);
   const size_t tiles = static_cast<size_t>(padded_tiles(n_points, precision));
-  *act_bytes = tiles * (s8 ? (t.act_pieces + 1) / 2 : t.act_pieces) * kPieceBytes;
+  *act_bytes = tiles * t.act_pieces * kPieceBytes;
   *mask_bytes = tiles * t.mask_words * kPieceBytes;
-  *grad_bytes = tiles * (s8 ? (t.grad_pieces + 1) / 2 : t.grad_pieces) * kPieceBytes;
+  *grad_bytes = tiles * t.grad_pieces * kPieceBytes;
   return 0;
 }
 
 extern "C" size_t dn_mlp_backward_packed_bytes(const dn_mlp_desc* desc, int precision) {
+  if (precision == DN_PREC_BF16_S8) {   // the 48-point chain's stream
+    if (validate_desc(desc, DN_PREC_BF16) || !g48_train_supported(*desc)) return 0;
+    NetLayout L48;
+    build_backward_layout48(*desc, &L48);
+    return static_cast<size_t>(L48.total_pieces) * kPieceBytes;
+  }
   if (validate_desc(desc, precision)) return 0;
   NetLayout L;
   build_backward_layout(*desc, precision, &L);
@@ -346,11 +349,11 @@ extern "C" size_t dn_mlp_backward_packed_bytes(const dn_mlp_desc* desc, int prec
 
 extern "C" int dn_mlp_pack_backward(const dn_mlp_desc* desc, int precision, const float* const* h_weights, void* packed,
                                     dn_stream_t stream) {
+  const bool s8 = precision == DN_PREC_BF16_S8;
+  if (s8) precision = DN_PREC_BF16;
   int rc = validate_desc(desc, precision);
   if (rc) return rc;
   DN_REQUIRE(h_weights && packed, "dn_mlp_pack_backward: NULL pointer");
-  NetLayout L;
-  build_backward_layout(*desc, precision, &L);
   const int n_params = desc->num_layers + (desc->use_viewdirs ? 4 : 1);
   PackPtrs ptrs{};
   for (int i = 0; i < n_params; ++i) {
@@ -358,6 +361,12 @@ extern "C" int dn_mlp_pack_backward(const dn_mlp_desc* desc, int precision, cons
     ptrs.w[i] = h_weights[i];
     ptrs.b[i] = h_weights[i];  // unused (no bias tiles in the backward stream)
   }
+  if (s8) {
+    DN_REQUIRE(g48_train_supported(*desc), "dn_mlp_pack_backward: no 8-bit-saved-tensor training kernels for this network");
+    return launch_pack48_backward(*desc, ptrs, static_cast<char*>(packed), as_stream(stream));
+  }
+  NetLayout L;
+  build_backward_layout(*desc, precision, &L);
   return launch_pack(L, ptrs, packed, precision, as_stream(stream));
 }
 
@@ -384,19 +393,23 @@ extern "C" int dn_run_network_train(const dn_mlp_desc* desc, int precision, cons
   p.n_points = n_rays * samples_per_ray;
   p.S = samples_per_ray;
   p.out = out;
-  TrainLayout t;
-  build_train_layout(*desc, precision, &t);
   p.act = static_cast<char*>(act);
   p.masks = static_cast<char*>(masks);
-  p.act_pieces = t.act_pieces; p.mask_words = t.mask_words;
-  if (s8) {
-    DN_REQUIRE(t.slot_xyz % 2 == 0 && t.slot_dir % 2 == 0 && t.slot_layer1 % 2 == 0 && t.slot_trunk0 % 2 == 0 && t.slot_feat % 2 == 0 &&
-               t.slot_dirout % 2 == 0, "dn_run_network_train (8-bit saved tensors): odd activation slot");
-    p.act_pieces = (t.act_pieces + 1) / 2;
+  if (s8) {   // the 48-point training forward: slots / strides in units of the s8-48 layout
+    DN_REQUIRE(g48_train_supported(*desc), "dn_run_network_train: no 8-bit-saved-tensor training kernels for this network (see dn_mlp_train_sizes)");
+    TrainLayout48 t8;
+    build_train_layout48(*desc, &t8);
+    p.act_pieces = t8.act_units; p.mask_words = t8.mask_stages;
+    p.slot_xyz = t8.slot_xyz; p.slot_dir = t8.slot_dir; p.slot_layer1 = t8.slot_layer1; p.slot_trunk0 = t8.slot_trunk0;
+    p.slot_feat = t8.slot_feat; p.slot_dirout = t8.slot_dirout;
     p.save8 = 1;
+  } else {
+    TrainLayout t;
+    build_train_layout(*desc, precision, &t);
+    p.act_pieces = t.act_pieces; p.mask_words = t.mask_words;
+    p.slot_xyz = t.slot_xyz; p.slot_dir = t.slot_dir; p.slot_layer1 = t.slot_layer1; p.slot_trunk0 = t.slot_trunk0;
+    p.slot_feat = t.slot_feat; p.slot_dirout = t.slot_dirout;
   }
-  p.slot_xyz = t.slot_xyz; p.slot_dir = t.slot_dir; p.slot_layer1 = t.slot_layer1; p.slot_trunk0 = t.slot_trunk0;
-  p.slot_feat = t.slot_feat; p.slot_dirout = t.slot_dirout;
   if (p.n_points == 0) return 0;
   return dispatch_forward(*desc, precision, p, as_stream(stream));
 }
@@ -411,6 +424,11 @@ extern "C" int dn_mlp_backward_data(const dn_mlp_desc* desc, int precision, cons
   DN_REQUIRE(packed_bwd && g_out && masks && grads && n_points >= 0, "dn_mlp_backward_data: bad arguments");
   DN_REQUIRE((reinterpret_cast<uintptr_t>(g_out) & 15) == 0, "dn_mlp_backward_data: g_out must be 16-byte aligned");
   if (n_points == 0) return 0;
+  if (s8) {   // the 48-point chain (mlp_train48.hip)
+    DN_REQUIRE(g48_train_supported(*desc), "dn_mlp_backward_data: no 8-bit-saved-tensor training kernels for this network (see dn_mlp_train_sizes)");
+    DN_REQUIRE(n_points < (1LL << 31) - 1024, "dn_mlp_backward_data (8-bit saved tensors): at most 2^31 - 1024 points per call");
+    return backward48_entry(desc, packed_bwd, g_out, masks, n_points, grads, g_s8_grad_scale.load(), as_stream(stream));
+  }
   NetLayout L;
   build_backward_layout(*desc, precision, &L);
   TrainLayout t;
@@ -429,14 +447,6 @@ extern "C" int dn_mlp_backward_data(const dn_mlp_desc* desc, int precision, cons
   p.gslot_dirout = t.gslot_dirout; p.gslot_feat = t.gslot_feat; p.gslot_trunk0 = t.gslot_trunk0; p.gslot_layer1 = t.gslot_layer1;
   p.gslot_out = t.gslot_out;
   const bool bf = precision == DN_PREC_BF16;
-  if (s8) {
-    DN_REQUIRE(t.gslot_dirout % 2 == 0 && t.gslot_feat % 2 == 0 && t.gslot_trunk0 % 2 == 0 && t.gslot_layer1 % 2 == 0 && t.gslot_out % 2 == 0,
-               "dn_mlp_backward_data (8-bit saved tensors): odd gradient slot");
-    p.grad_pieces = (t.grad_pieces + 1) / 2;
-    p.grad_scale = g_s8_grad_scale.load();
-    if (desc->hidden_size == 256) return launch_backward<256, 1, true>(p, as_stream(stream));
-    if (desc->hidden_size == 128) return launch_backward<128, 1, true>(p, as_stream(stream));
-  }
   if (desc->hidden_size == 256) return bf ? launch_backward<256, true>(p, as_stream(stream)) : launch_backward<256, false>(p, as_stream(stream));
   if (desc->hidden_size == 128) return bf ? launch_backward<128, true>(p, as_stream(stream)) : launch_backward<128, false>(p, as_stream(stream));
   set_error("dn_mlp_backward_data: no kernel instance for W=%d", desc->hidden_size);
@@ -445,6 +455,14 @@ extern "C" int dn_mlp_backward_data(const dn_mlp_desc* desc, int precision, cons
 
 extern "C" int dn_mlp_unpack(const dn_mlp_desc* desc, int precision, int which, const void* native, int64_t n_points,
                              int slot, int width, int kind, float* out, int ld_out, int col0, dn_stream_t stream) {
+  if (precision == DN_PREC_BF16_S8) {   // the 8-bit units of the 48-point training kernels (kind 3: the custom output-gradient unit)
+    int rc8 = validate_desc(desc, DN_PREC_BF16);
+    if (rc8) return rc8;
+    DN_REQUIRE(native && out && n_points >= 0 && width > 0 && ld_out >= col0 + 1 && (which == 0 || which == 1) && kind >= 0 && kind <= 3 &&
+               g48_train_supported(*desc), "dn_mlp_unpack (8-bit layout): bad arguments");
+    if (n_points == 0) return 0;
+    return unpack48_entry(desc, which, native, n_points, slot, width, kind, out, ld_out, col0, g_s8_grad_scale.load(), as_stream(stream));
+  }
   int rc = validate_desc(desc, precision);
   if (rc) return rc;
   DN_REQUIRE(native && out && n_points >= 0 && width > 0 && ld_out >= col0 + 1 && (which == 0 || which == 1) && kind >= 0 && kind <= 2,
@@ -501,6 +519,7 @@ struct WgParams {
   int custom_rows;                // custom dY piece: element (half h, e) = output row 8h+e, rows < custom_rows real
   int x_slot;                     // hidden X pieces (2 per 32-feature tile)
   int pe_slot, pe_L;              // positional-encoding pieces appended to X
+  int pe_kind;                    // 1 xyz, 2 view direction (the 8-bit layout keeps the two panels differently: mlp_geo48.h)
   float* dW;
   int ldw, col_pe0;
   float* db;
@@ -544,8 +563,12 @@ struct WgShape {
   static constexpr int KGROUPS = 8 / NTN;                  // waves sharing one n-tile split the k-tiles
   static constexpr int J = (KT + KGROUPS - 1) / KGROUPS;   // k-tiles (accumulators) per wave
   static constexpr int UPT = S8 ? 1 : 2;                   // staged 1 KiB units per 32-feature tile
-  static constexpr int N_DY = CUSTOM ? 1 : UPT * NTN;
-  static constexpr int N_X = UPT * XT, N_PE = UPT * PET;
+  // 8-bit buffers (s8-48 layout, mlp_geo48.h): a 32-point record holds, per 64-feature slot, the unit of its first and of its
+  // second 16-point group side by side - so units come in pairs: a 32-feature tile is half of the two units of its slot, and a
+  // lone custom dY piece / the one-piece view-direction panel still stage a whole pair
+  static constexpr int N_DY = CUSTOM ? (S8 ? 2 : 1) : UPT * NTN;
+  static constexpr int N_X = UPT * XT, N_PE = S8 ? 2 * ((PET + 1) / 2) : UPT * PET;
+  static_assert(!S8 || (XT % 2 == 0 && (CUSTOM || NTN % 2 == 0)), "8-bit layout: whole 64-feature slots");
   static constexpr int PIECES = N_DY + N_X + N_PE;         // 1 KiB pieces staged per 32-point tile
   static constexpr int PER_WAVE = (PIECES + 7) / 8;        // DMAs per tile of the busiest wave
   // 8-bit kernel: PAIRS of tiles contracted by the K = 64 fp8 MFMA (twice the K = 16 rate) wherever 24 operand registers fit
@@ -628,7 +651,11 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
   // bytes apart modulo the 128-byte bank period: a group covers all 32 banks once.  (Reading the two lane halves of ONE piece side by
   // side put them 512 B apart = on the same 16 banks: stamps showed 2,242 cycles of `consume` per 256 x 256 tile for 1,152 cycles
   // of MFMAs, PMC three conflict cycles in four LDS cycles.)
-  const int lane_off = S::S8 ? ((fs * 32 + (li >> 1)) * 16) + (li & 1) * 8
+  // 8-bit units (s8-48 layout): unit rows are (lane group g, point j of the 16-point group), 16 bytes each = the 8 + 8 bytes of
+  // the slot's two pieces; a 32-feature fragment of parity par takes rows g = 2 par + fs, a 16-lane group reads 8 of them (128
+  // contiguous bytes, every LDS bank once): lane li supplies the 8-byte chunk (row li >> 1, half li & 1) and receives byte
+  // column li.  Parity 1 sits 512 bytes further on; the record's second group one unit (PS) further on.
+  const int lane_off = S::S8 ? ((fs * 16 + (li >> 1)) * 16) + (li & 1) * 8
                              : ((li & 3) >> 1) * PS + ((fs * 32 + (li >> 2) + 8 * hh) * 16) + ((li & 3) & 1) * 8;
 
   // ---- staging: each 1 KiB piece is one LDS-DMA (opaque asm: the counted waits below are ours; hipcc would drain
@@ -747,17 +774,21 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
     typedef int i32x8 __attribute__((ext_vector_type(8)));
     const char* base = smem + (hh ? cb1 : cb0) * BUF + lane_off;
     constexpr int kOnes = 0x38383838;   // 1.0 in e4m3, four times
-    auto read32 = [](const char* unit_lane) {   // this lane's 32 K slots of one operand: four 8-point transposing reads
+    // this lane's 32 K slots of one operand = the 32 points of its record: four 8-point transposing reads, two in the unit of
+    // the record's first 16-point group, two in the second group's (the next staged unit)
+    auto read32 = [](const char* unit_lane) {
       i32x8 o;
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(unit_lane + f * 128));
+        const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(unit_lane + (f >> 1) * kPieceBytes + (f & 1) * 128));
         o[2 * f] = v[0]; o[2 * f + 1] = v[1];
       }
       return o;
     };
-    // A = dY^T: unit `ntile` holds both pieces of the n-tile (fragment row 16 fs + li = piece li >> 3, lane half fs, element li & 7)
-    i32x8 av = read32(base + (S::CUSTOM ? 0 : ntile * kPieceBytes));
+    // 32-feature fragment `frag` of a staged vector that starts at unit `first`: slot frag / 2 (two staged units), row parity frag % 2
+    auto frag_at = [&](int first, int frag) { return base + (first + 2 * (frag >> 1)) * kPieceBytes + (frag & 1) * 512; };
+    // A = dY^T (fragment row 16 fs + li = lane group 2 (ntile % 2) + fs, byte li of the unit row: piece li >> 3, element li & 7)
+    i32x8 av = read32(frag_at(0, S::CUSTOM ? 0 : ntile));
     const long long mine = hh ? tile1 : tile0;
     // points of this lane's tile that exist (the rest: padding copies, or a re-load standing in for an absent tile); a custom dY
     // is piece dy_odd of its unit: the columns of the other piece are not its rows
@@ -779,7 +810,7 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
           for (int d = 0; d < 8; ++d) bv[d] = kOnes;
         } else {
 #ifndef DN_WG_NOREAD
-          bv = read32(base + (S::N_DY + j) * kPieceBytes);
+          bv = read32(frag_at(j < S::XT ? S::N_DY : S::N_DY + S::N_X, j < S::XT ? j : j - S::XT));
 #else
 #pragma unroll
           for (int d = 0; d < 8; ++d) bv[d] = kOnes;
@@ -787,8 +818,8 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
         }
       } else {
         const int kt = kgroup + j * S::KGROUPS;           // wave-uniform; kt >= KT: an unused accumulator
-        const int ktr = kt < S::KT - 1 ? kt : S::KT - 2;  // a unit that exists
-        bv = read32(base + (S::N_DY + ktr) * kPieceBytes);
+        const int ktr = kt < S::KT - 1 ? kt : S::KT - 2;  // a fragment that exists
+        bv = read32(frag_at(ktr < S::XT ? S::N_DY : S::N_DY + S::N_X, ktr < S::XT ? ktr : ktr - S::XT));
         const bool is_ones = kt >= S::KT - 1;
 #pragma unroll
         for (int d = 0; d < 8; ++d) bv[d] = is_ones ? kOnes : bv[d];
@@ -823,58 +854,9 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
       });
     }
   };
-  // 8-bit buffers, one tile, K = 16 MFMAs: the shapes whose accumulators leave no room for the K = 64 operands (S::K64 false)
-  auto consume_s8 = [&](long long tile, int cb) {
-    const char* base = smem + cb * BUF + lane_off + hh * 128;   // (K = 16: lane group hh reads points 8 hh .. 8 hh + 7 of each 16)
-    constexpr long kOnes = 0x3838383838383838L;   // 1.0 in e4m3, eight times
-    // A = dY^T (e5m2): unit `ntile` holds both pieces of the n-tile (fragment row 16 fs + li = piece li >> 3, lane half fs, element li & 7)
-    const char* dy = base + (S::CUSTOM ? 0 : ntile * kPieceBytes);
-    long a0 = tr8_frag(dy, 0);
-    long a1 = tr8_frag(dy, 16);
-    if constexpr (S::CUSTOM) {   // a custom dY is piece dy_odd of its unit: the columns of the other piece are not its rows
-      a0 = ((li >> 3) != p.dy_odd) ? 0L : a0;
-      a1 = ((li >> 3) != p.dy_odd) ? 0L : a1;
-    }
-    const long long valid = p.n_points - tile * 32;  // points of this tile that exist (the rest are padding copies)
-    if (valid < 32) {
-      auto keep = [&](int first) -> long {   // bytes of the points first .. first+7 that exist
-        const long long n = valid - first;
-        return n >= 8 ? -1L : (n <= 0 ? 0L : static_cast<long>((1ull << (8 * n)) - 1ull));
-      };
-      a0 &= keep(8 * hh);
-      a1 &= keep(16 + 8 * hh);
-    }
-    static_for<S::J>([&](auto j_c) {
-      constexpr int j = decltype(j_c)::value;
-      long b0, b1;
-      if constexpr (S::KGROUPS == 1) {
-        if constexpr (j == S::KT - 1) { b0 = kOnes; b1 = kOnes; }
-        else {
-#ifndef DN_WG_NOREAD
-          const char* pb = base + (S::N_DY + j) * kPieceBytes;
-          b0 = tr8_frag(pb, 0);
-          b1 = tr8_frag(pb, 16);
-#else
-          b0 = kOnes; b1 = kOnes;
-#endif
-        }
-      } else {
-        const int kt = kgroup + j * S::KGROUPS;           // wave-uniform; kt >= KT: an unused accumulator
-        const int ktr = kt < S::KT - 1 ? kt : S::KT - 2;  // a unit that exists
-        const char* pb = base + (S::N_DY + ktr) * kPieceBytes;
-        b0 = tr8_frag(pb, 0);
-        b1 = tr8_frag(pb, 16);
-        const bool is_ones = kt >= S::KT - 1;
-        b0 = is_ones ? kOnes : b0;
-        b1 = is_ones ? kOnes : b1;
-      }
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a0, b0, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a1, b1, acc[j], 0, 0, 0);
-    });
-  };
+  static_assert(!S::S8 || S::K64, "every 8-bit shape contracts pairs of tiles (K = 64)");
   auto consume = [&](long long tile, int cb) {
-    if constexpr (S::S8) consume_s8(tile, cb);
-    else consume_16(tile, cb);
+    if constexpr (!S::S8) consume_16(tile, cb);
   };
   // tile k of this workgroup's sequence (k = 0, 1, ...) is 32-point tile wg + k * n_wg and lives in buffer k % STAGES
   int buf = 0;
@@ -1022,19 +1004,31 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
       auto piece_of = [](int i) { return (i >> 3) & 1; };
       auto half_of = [](int i) { return i >> 4; };
       auto feature_of = [&](int i) { return acc_row(piece_of(i) * 8 + (i & 7), half_of(i)); };
+      // 8-bit layout: fragment `frag` of a hidden vector, index i = 16 fs + li -> lane group 2 (frag % 2) + fs, piece
+      // 2 (frag / 2) + li / 8, element li % 8 (g48_hidden_col); relative to the vector's first feature
+      auto feature48 = [&](int frag, int i) { return g48_hidden_col(2 * (frag >> 1) + piece_of(i), 2 * (frag & 1) + half_of(i), i & 7); };
       int col;
-      if (kt < S::XT) col = 32 * kt + feature_of(jl);
+      if (kt < S::XT) col = S::S8 ? feature48(kt, jl) : 32 * kt + feature_of(jl);
       else if (kt < S::KT - 1) {
-        const int pe_piece = 2 * (kt - S::XT) + piece_of(jl);
-        const int pc = pe_slot_col(p.pe_L, half_of(jl), pe_piece * 8 + (jl & 7));
+        int pc;
+        if constexpr (S::S8) {
+          // xyz panel (two fragments): lane group 2 (fragment) + fs, slot = byte li; view-direction panel (one fragment): lanes of
+          // groups 0 / 1 hold [their 8 slots | those of groups 2 / 3]
+          const int li_c = jl & 15, fs_c = jl >> 4;
+          pc = p.pe_kind == 1 ? g48_pe_col(1, 2 * (kt - S::XT) + fs_c, li_c, p.pe_L) : g48_pe_col(2, fs_c + 2 * (li_c >> 3), li_c & 7, p.pe_L);
+        } else {
+          const int pe_piece = 2 * (kt - S::XT) + piece_of(jl);
+          pc = pe_slot_col(p.pe_L, half_of(jl), pe_piece * 8 + (jl & 7));
+        }
         col = pc >= 0 ? p.col_pe0 + pc : -1;
       } else col = (jl == 0) ? -2 : -1;  // all-ones tile: column 0 carries the bias gradient
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int irow = acc_row(r, half);
-        int n = 32 * ntile + feature_of(irow);
+        int n = S::S8 ? feature48(ntile, irow) : 32 * ntile + feature_of(irow);
         if constexpr (S::CUSTOM) {
-          // custom piece: row = 8h + e (bf16: piece 0 of the pair read; 8-bit: piece dy_odd of the unit - the other one was zeroed)
+          // custom piece: row = 8 (lane half / lane group) + e (bf16: piece 0 of the pair read; 8-bit: piece dy_odd of the unit - the
+          // other one was zeroed)
           const bool mine = piece_of(irow) == (S::S8 ? p.dy_odd : 0);
           n = mine ? half_of(irow) * 8 + (irow & 7) : p.custom_rows;
           if (n >= p.custom_rows) continue;
@@ -1349,6 +1343,7 @@ static int wg_fill(const dn_mlp_desc* desc, const TrainLayout& t, const void* ac
   p.pe_slot = pe_kind == 1 ? t.slot_xyz : t.slot_dir;
   const int pe_tiles = pe_kind == 0 ? 0 : (pe_kind == 1 ? t.kxp : t.kdp) / t.ppt;   // pieces per 32-column tile: 2 (bf16) / 4 (fp32)
   p.pe_L = pe_kind == 1 ? desc->num_encoding_fn_xyz : desc->num_encoding_fn_dir;
+  p.pe_kind = pe_kind;
   p.dW = dW; p.ldw = ldw; p.col_pe0 = x_width; p.db = db;
   p.shape = wg_shape_index(n_out / 32, x_width / 32, pe_tiles, custom_rows > 0);
   if (p.shape < 0) {
@@ -1356,8 +1351,9 @@ static int wg_fill(const dn_mlp_desc* desc, const TrainLayout& t, const void* ac
     return DN_E_UNSUPPORTED;
   }
   if (s8) {
-    // 8-bit buffers: two pieces side by side per 1 KiB unit - every slot / stride in units; all piece slots of a layer are even
-    // except a custom dY piece (fc_rgb: even half, fc_alpha: odd half of the last unit)
+    // 8-bit buffers (s8-48 layout): `t` carries the layout in HALF-unit numbers (wg_layout_s8): two pieces side by side per 1 KiB
+    // unit - every slot / stride below becomes a count of staged units; all slots of a layer are even except a custom dY piece
+    // (fc_rgb: even half, fc_alpha: odd half of the custom unit)
     DN_REQUIRE(custom_rows || (p.g_slot % 2) == 0, "weight_grad (8-bit buffers): odd gradient slot");
     DN_REQUIRE((p.x_slot % 2) == 0 && (p.pe_slot % 2) == 0, "weight_grad (8-bit buffers): odd activation slot");
     p.dy_odd = p.g_slot & 1;
@@ -1369,51 +1365,27 @@ static int wg_fill(const dn_mlp_desc* desc, const TrainLayout& t, const void* ac
   return 0;
 }
 
+// The s8-48 layout (TrainLayout48: units per 16-point group) in the numbering wg_fill halves for the 8-bit kernel: a record of two
+// groups holds 2 x units_per_group staged units, the two groups' units of slot s at staged positions 2 s and 2 s + 1 - so slot s is
+// "half-unit" 4 s, a hidden vector spans 4 kh_u of them, and the custom unit's second piece (d alpha) is half-unit 4 s + 1.
+static void wg_layout_s8(const dn_mlp_desc& d, TrainLayout* t) {
+  TrainLayout48 u;
+  build_train_layout48(d, &u);
+  *t = TrainLayout{};
+  t->kpp = 16; t->epp = 8; t->ppt = 2;
+  t->kxp = 4; t->kdp = d.use_viewdirs ? 2 : 0;   // -> 2 / 1 32-column tiles (wg_fill)
+  t->kh = 4 * u.kh_u;
+  t->slot_xyz = 4 * u.slot_xyz; t->slot_dir = 4 * u.slot_dir; t->slot_layer1 = 4 * u.slot_layer1; t->slot_trunk0 = 4 * u.slot_trunk0;
+  t->slot_feat = 4 * u.slot_feat; t->slot_dirout = 4 * u.slot_dirout;
+  t->act_pieces = 4 * u.act_units;
+  t->mask_words = u.mask_stages;
+  t->gslot_dirout = 4 * u.gslot_dirout; t->gslot_feat = 4 * u.gslot_feat; t->gslot_trunk0 = 4 * u.gslot_trunk0; t->gslot_layer1 = 4 * u.gslot_layer1;
+  t->gslot_out = 4 * u.gslot_out;
+  t->grad_pieces = 4 * u.grad_units;
+}
+
 template <class K>
 static int wg_attr(K kern) { return ensure_big_lds(reinterpret_cast<const void*>(kern)); }
-
-// bf16 native pieces -> 8-bit units (two pieces side by side): e4m3 for activations (WHICH = 0), e5m2 times `scale` for
-// gradients (WHICH = 1).  Test scaffolding for the 8-bit weight-gradient kernel and the reference of what the training kernels
-// store directly in DN_PREC_BF16_S8.
-template <int WHICH>
-__global__ void convert_s8_kernel(const char* __restrict__ native, long long n_tiles, int pieces, float scale, char* __restrict__ out) {
-  const int units = (pieces + 1) / 2;
-  const long long total = n_tiles * units * 64;
-  for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
-       idx += static_cast<long long>(gridDim.x) * blockDim.x) {
-    const int lane = static_cast<int>(idx % 64);
-    const long long tu = idx / 64;
-    const int unit = static_cast<int>(tu % units);
-    const long long tile = tu / units;
-    int words[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int piece = 2 * unit + half;
-      if (piece >= pieces) continue;
-      const __bf16* src = reinterpret_cast<const __bf16*>(native + ((tile * pieces + piece) * 64 + lane) * 16);
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] = static_cast<float>(src[e]) * scale;
-        // saturate: e5m2 has infinities, e4m3 turns an overflow into NaN (same clamps as piece_to_8bit: the bytes must agree)
-        v[e] = __builtin_amdgcn_fmed3f(v[e], WHICH == 1 ? -kE5m2Max : -kE4m3Max, WHICH == 1 ? kE5m2Max : kE4m3Max);
-      }
-#pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        int w = 0;
-        if constexpr (WHICH == 0) {
-          w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * d], v[4 * d + 1], w, false);
-          w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * d + 2], v[4 * d + 3], w, true);
-        } else {
-          w = __builtin_amdgcn_cvt_pk_bf8_f32(v[4 * d], v[4 * d + 1], w, false);
-          w = __builtin_amdgcn_cvt_pk_bf8_f32(v[4 * d + 2], v[4 * d + 3], w, true);
-        }
-        words[half * 2 + d] = w;
-      }
-    }
-    *reinterpret_cast<int4*>(out + ((tile * units + unit) * 64 + lane) * 16) = make_int4(words[0], words[1], words[2], words[3]);
-  }
-}
 
 }  // namespace dn
 
@@ -1429,7 +1401,12 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
   DN_REQUIRE(desc->num_encoding_fn_xyz == 10, "dn_mlp_weight_grad_all: training kernels are built for L_xyz = 10");
   if (n_points == 0) return 0;
   TrainLayout t;
-  build_train_layout(*desc, precision, &t);
+  if (s8) {
+    DN_REQUIRE(g48_train_supported(*desc), "dn_mlp_weight_grad_all: no 8-bit-saved-tensor training kernels for this network (see dn_mlp_train_sizes)");
+    wg_layout_s8(*desc, &t);
+  } else {
+    build_train_layout(*desc, precision, &t);
+  }
   NetLayout L;
   build_layout(*desc, precision, &L);
   const int W = desc->hidden_size, D = desc->num_layers;
@@ -1558,22 +1535,4 @@ extern "C" int dn_set_s8_grad_scale(float scale) {
              "dn_set_s8_grad_scale: the scale must be a power of two (the scaling and its inverse are then exact)");
   g_s8_grad_scale.store(scale);
   return 0;
-}
-
-extern "C" int dn_mlp_convert_saved_s8(const dn_mlp_desc* desc, int which, const void* native_bf16, int64_t n_points, void* out_s8,
-                                       dn_stream_t stream) {
-  int rc = validate_desc(desc, DN_PREC_BF16);
-  if (rc) return rc;
-  DN_REQUIRE((which == 0 || which == 1) && native_bf16 && out_s8 && n_points >= 0, "dn_mlp_convert_saved_s8: bad arguments");
-  if (n_points == 0) return 0;
-  TrainLayout t;
-  build_train_layout(*desc, DN_PREC_BF16, &t);
-  const long long tiles = padded_tiles(n_points, DN_PREC_BF16);
-  if (which == 0)
-    hipLaunchKernelGGL(convert_s8_kernel<0>, dim3(2048), dim3(256), 0, as_stream(stream), static_cast<const char*>(native_bf16), tiles,
-                       t.act_pieces, 1.0f, static_cast<char*>(out_s8));
-  else
-    hipLaunchKernelGGL(convert_s8_kernel<1>, dim3(2048), dim3(256), 0, as_stream(stream), static_cast<const char*>(native_bf16), tiles,
-                       t.grad_pieces, g_s8_grad_scale.load(), static_cast<char*>(out_s8));
-  return check_launch("dn_mlp_convert_saved_s8");
 }

@@ -1,0 +1,440 @@
+// Backward-data chain of the fused network in the 48-points-per-wave geometry (the training mode with 8-bit saved tensors,
+// DN_PREC_BF16_S8; reference: loss.backward() through FlexibleNeRFModel.forward, nerf/models.py:233-256,
+// train_dexnerf_rgb.py:278).  The forward of this mode is mlp_forward48_kernel<..., SAVE = 2> (mlp_fused48.hip).
+//
+// Same formulation as mlp_backward_kernel (mlp_train.hip) - dX^T[K x points] = W^T[K x N] . dY^T[N x points] on the
+// TRANSPOSED weight stream, the masked gradient tile of one stage being the B operand of the next - on
+// v_mfma_f32_16x16x32_bf16: every A fragment read from LDS feeds three MFMAs (three 16-point groups per wave, 384 points per
+// pass of the stream instead of 256), the explicit LDS read pipeline and the asymmetric weight fetch of the inference
+// kernel (mlp_stage48.h).  The ReLU mask words come from the 48-point forward lane for lane: accumulator register r of tile nt
+// of a backward stage is the same (feature, point) as in the forward stage whose output it differentiates, so no bit
+// transpose is needed (mlp_geo48.h).  Every masked dL/d(pre-activation) is stored once, as e5m2 of (gradient x scale), in the
+// s8-48 unit layout the weight-gradient kernel contracts (mlp_train.hip).
+#include "mlp_stage48.h"
+
+namespace dn {
+
+struct Bwd48Params {
+  const char* packed;      // backward (transposed) piece stream of build_backward_layout48, no bias region
+  int total_pieces;
+  int D, use_viewdirs;
+  const float* g_out;      // (P, 4) dL/d[r, g, b, sigma] of the raw radiance field
+  const char* masks;       // mask words of the training forward
+  int mask_stages;
+  long long n_points;
+  int n_tiles;             // 384-point workgroup tiles
+  char* grads;             // saved gradients, s8-48 units
+  int grad_units;
+  int gslot_dirout, gslot_feat, gslot_trunk0, gslot_layer1, gslot_out;
+  float inv_scale;         // 1 / (the power of two the gradients are multiplied by before they are rounded to e5m2)
+  float clamp_hi, clamp_lo;   // +-57344 / scale: a gradient beyond saturates (e5m2 has infinities; the converts do not saturate).  Two
+                              // parameters, not one negated in the kernel: CodeGenPrepare sinks a copy of the (free) fneg to each of its
+                              // thousands of uses in the unrolled tile pass and takes ten minutes over it
+};
+
+constexpr int kBwd48WaveLds = 8 * kPieceBytes;   // per wave: 2 output-gradient slots (1 KiB) + 3 mask-word slots (2 KiB)
+
+// masked gradient tile -> elements of the next stage's B piece + (every fourth tile) one saved unit
+//   mw: this group's mask dwords (lo: tiles 0-7, hi: tiles 8-15), bit layout of mlp_geo48.h
+template <int NT, class BO>
+__device__ __forceinline__ void emit_grad48(const f32x4& acc, unsigned mw_lo, unsigned mw_hi, float lo, float hi, BO& bo) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w = __builtin_bit_cast(u32x4, bo[NT / 2]);
+  const unsigned word = (NT >> 3) ? mw_hi : mw_lo;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    // saturate in fp32, before the 16-bit rounding: the saved e5m2 byte is then formed straight from the 16-bit pair
+    const f32x2 f = {__builtin_amdgcn_fmed3f(acc[2 * d], lo, hi), __builtin_amdgcn_fmed3f(acc[2 * d + 1], lo, hi)};
+    const unsigned pair = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+    // mask bits of registers 2d / 2d+1 sit at position p and p + 16: (bits & 0x00010001) * 0xFFFF = the AND mask of the pair
+    const unsigned keep = __umul24((word >> ((NT & 7) * 2 + d)) & 0x00010001u, 0xFFFFu);
+    w[(NT & 1) * 2 + d] = pair & keep;
+  }
+  bo[NT / 2] = __builtin_bit_cast(bf16x8, w);
+}
+
+// W: hidden width; DC > 0: depth fixed at compile time (with VIEWC the view-direction branch) - the tile pass is straight-line
+// code, one settle at its end (mlp_fused48.hip); DC = 0: run-time depth / branch, one settle per stage.
+template <int W, int DC = 0, int VIEWC = 0>
+__global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48Params p) {
+  constexpr int F = 1;
+  constexpr bool FIXED = DC > 0;
+  constexpr bool ST = !FIXED;
+  constexpr int PH = kPhasePieces;   // (the two-phase barrier form waits with vmcnt(0): with this kernel's stores in the queue that would be for HBM)
+  using BP8 = bf16x8;
+  constexpr int PT = 3;
+  constexpr int NT = W / 16;
+  constexpr int KH = W / 32;
+  constexpr int KHU = KH / 2;
+  constexpr int WAVES = kG48Waves;
+  constexpr int PPW = kG48PointsPerWave;
+  constexpr int PPG = kG48PointsPerWg;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // per-wave staging: the output-gradient rows of the NEXT tile and the mask words two stages ahead arrive by LDS-DMA; no
+  // VGPR-destination global load exists in the tile loop (mlp_train.hip)
+  char* wbuf = smem + kRingBytes + wave * kBwd48WaveLds;
+  const unsigned wbuf_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)wbuf));
+  const int n_masks = FIXED ? (DC - 1) + (VIEWC ? 2 : 0) : p.mask_stages;   // stage q < n_masks applies mask n_masks-1-q; the last stage none
+  const int n_points = static_cast<int>(p.n_points);   // (launches of >= 2^31 - 1024 points are refused by the host side)
+
+  auto issue_gout = [&](int tile, int slot) {
+    int pt = tile * PPG + wave * PPW + lane;   // lanes 48..63 stage rows nobody reads (inside the slot's 1 KiB)
+    if (pt >= n_points) pt = n_points - 1;
+    dma16_lanes(p.g_out + static_cast<long long>(pt) * 4, wbuf_addr + slot * kPieceBytes);
+  };
+  auto issue_mask = [&](int tile, int q) {  // both mask words of stage q of `tile` -> slot q % 3
+    const char* src = p.masks + ((static_cast<long long>(tile) * WAVES + wave) * p.mask_stages + (n_masks - 1 - q)) * (2 * kPieceBytes) + lane * 16;
+    const unsigned dst = wbuf_addr + 2 * kPieceBytes + (q % 3) * (2 * kPieceBytes);
+    dma16_lanes(src, dst);
+    dma16_lanes(src + kPieceBytes, dst + kPieceBytes);
+  };
+
+  Pipe<WAVES> pipe;
+  pipe.ring = ring;
+  pipe.ring_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)ring));
+  pipe.lane16 = lane * 16;
+  pipe.wsrc = p.packed;
+  pipe.total_bytes = static_cast<unsigned>(p.total_pieces) * kPieceBytes;
+  pipe.q_issue = 0;
+  pipe.slot_wr = 0;
+  pipe.wave = wave;
+  issue_gout(blockIdx.x, 0);
+  issue_mask(blockIdx.x, 0);
+  if (n_masks > 1) issue_mask(blockIdx.x, 1);
+#pragma unroll
+  for (int ph = 0; ph < kRingPhases - 1; ++ph) pipe.issue_phase();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  pipe.slot_nxt = 0;
+  pipe.rda_cur = pipe.ring_addr + lane * 16;
+  pipe.slot_cur_base = pipe.ring_addr;       // phase 0 lives in slot 0: phase_begin() of phase 0 turns this into rda_cur
+  static_for<kPrefetch>([&](auto e_c) { pipe.template prologue_read<decltype(e_c)::value>(); });
+
+  int g_slot = 0;
+  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    // this wave's three point groups' saved-gradient bases (wave-uniform; every store adds a small offset)
+    const char* grad_grp[PT];
+    {
+      const long long wt = static_cast<long long>(tile) * WAVES + wave;
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        const long long G = wt * PT + t;
+        grad_grp[t] = uniform_ptr(p.grads + ((G >> 1) * p.grad_units * 2 + (G & 1)) * kPieceBytes);
+      }
+    }
+    // two 16-bit pairs -> four e5m2 bytes of (gradient x scale)
+    auto to_e5m2 = [&](unsigned d0, unsigned d1) {
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      s16x2 r = {0, 0};
+      r = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(r, __builtin_bit_cast(bf16x2, d0), p.inv_scale, false);
+      r = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(r, __builtin_bit_cast(bf16x2, d1), p.inv_scale, true);
+      return __builtin_bit_cast(unsigned, r);
+    };
+    auto save_unit = [&](auto t_c, int slot, const BP8& lo, const BP8& hi) {
+      constexpr int t = decltype(t_c)::value;
+      const u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
+      store16_uniform_at(grad_grp[t], static_cast<unsigned>(slot) * (2 * kPieceBytes), pipe.lane16,
+                         make_uint4(to_e5m2(a[0], a[1]), to_e5m2(a[2], a[3]), to_e5m2(b[0], b[1]), to_e5m2(b[2], b[3])));
+    };
+
+    // ---- the output gradient of this lane's points: lane group 0 carries it (custom pieces: k = 8 g + e) ----
+    float gv[PT][4];
+    {
+      const int j = lane & 15;
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wbuf + g_slot * kPieceBytes + (t * 16 + j) * 16);
+        const int pt = tile * PPG + wave * PPW + t * 16 + j;
+        const bool live = (lane < 16) && (pt < n_points);   // padding points (clamped copies in the forward) contribute nothing
+        // (saturated like every other gradient of the chain: the custom pieces are stored as e5m2 too)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gv[t][c] = live ? __builtin_amdgcn_fmed3f(v[c], p.clamp_lo, p.clamp_hi) : 0.0f;
+      }
+    }
+    // Start of stage q: fetch this stage's mask words from their LDS slot, then stage what will be needed two stages on (same
+    // tile, or the first two stages / the output gradient of the next tile) into the slot read one stage ago.  The LDS reads
+    // are complete (lgkmcnt(0)) before a DMA may overwrite a slot.
+    unsigned mw[PT][2];
+    auto stage_begin = [&](int q) {
+      {
+        // (read unconditionally - the slot exists for every q - and select: no branch around an LDS read in the MFMA stream)
+        const char* slot = wbuf + 2 * kPieceBytes + (q % 3) * (2 * kPieceBytes) + lane * 16;
+        const uint4 w0 = *reinterpret_cast<const uint4*>(slot);
+        const uint2 w1 = *reinterpret_cast<const uint2*>(slot + kPieceBytes);
+        const unsigned all = (q < n_masks) ? 0u : ~0u;   // the last stage has no mask
+        mw[0][0] = w0.x | all; mw[0][1] = w0.y | all; mw[1][0] = w0.z | all; mw[1][1] = w0.w | all; mw[2][0] = w1.x | all; mw[2][1] = w1.y | all;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int r = q + 2;
+      if (r < n_masks) issue_mask(tile, r);
+      else if (r > n_masks && nxt < p.n_tiles) {   // r == n_masks + 1 / + 2: stages 0 / 1 of the next tile
+        const int r2 = r - (n_masks + 1);
+        if (r2 < n_masks) issue_mask(nxt, r2);
+        if (r2 == 0) issue_gout(nxt, g_slot ^ 1);
+      }
+    };
+    auto emit_to = [&](auto nt_c, auto t_c, const f32x4& acc, auto& bout, int gslot) {
+      constexpr int nt = decltype(nt_c)::value, t = decltype(t_c)::value;
+      emit_grad48<nt>(acc, mw[t][0], mw[t][1], p.clamp_lo, p.clamp_hi, bout[t]);
+      if constexpr (nt % 4 == 3) save_unit(t_c, gslot + nt / 4, bout[t][nt / 2 - 1], bout[t][nt / 2]);
+    };
+
+    BP8 ba[PT][KH], bb[PT][KH];
+    BP8 none[PT][1];
+    auto no_pe = [&](int, int) { return BP8{}; };
+    int q = 0;  // stage counter of this tile
+    // custom K pieces: element e of lane group 0 carries k = e
+    auto custom_piece = [&](int t, int first, int count) {
+      BP8 c{};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < count) c[e] = static_cast<__bf16>(gv[t][first + e]);
+      return c;
+    };
+    // trunk, i = D-2 .. 0:  d x_i = layers_xyz[i][:, :W]^T d pre_i, masked by relu'(x_i) (x_0 = layer1's output: the last stage has
+    // no mask word - stage_begin hands back all ones).  The gradient sets ping-pong between `ba` and `bb`; every trunk stage is a
+    // whole number of phases, so they all start at the position the head stages leave (POS).
+    auto trunk = [&](auto pos_c, auto depth_c) __attribute__((always_inline)) {
+      constexpr int POS = decltype(pos_c)::value;
+      constexpr int PAD = (kPhasePieces - POS % kPhasePieces) % kPhasePieces;
+      static_assert((NT * KH) % kPhasePieces == 0, "trunk stages must preserve the phase offset");
+      auto layer = [&](int i, const BP8 (&bin)[PT][KH], BP8 (&bout)[PT][KH], auto last_c) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_c)::value;
+        stage_begin(q++);
+        const int gslot = i > 0 ? p.gslot_trunk0 + (i - 1) * KHU : p.gslot_layer1;
+        run_stage48<F, NT, KH, 0, POS, LAST, ST, (LAST ? PAD : 0), PH, 0, false>(pipe, bin, no_pe, 0u, 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
+          emit_to(nt_c, t_c, acc, bout, gslot);
+        });
+      };
+      constexpr int DD = decltype(depth_c)::value;
+      if constexpr (DD > 0) {
+        // fixed depth: straight-line code
+        static_for<DD - 1>([&](auto s_c) {
+          constexpr int s = decltype(s_c)::value;
+          constexpr int i = DD - 2 - s;
+          if constexpr (s % 2 == 0) layer(i, ba, bb, std::integral_constant<bool, i == 0>{});
+          else layer(i, bb, ba, std::integral_constant<bool, i == 0>{});
+        });
+      } else {
+        int i = p.D - 2;
+        for (; i >= 2; i -= 2) {
+          layer(i, ba, bb, std::false_type{});
+          layer(i - 1, bb, ba, std::false_type{});
+        }
+        if (i == 1) {
+          layer(1, ba, bb, std::false_type{});
+          layer(0, bb, ba, std::true_type{});
+        } else {
+          layer(0, ba, bb, std::true_type{});
+        }
+      }
+      if constexpr (PAD != 0) pipe.template skip<POS + NT * KH, PAD, PH, false>();   // (settles at its end)
+      else pipe.template settle<false>();
+    };
+    auto with_viewdirs = [&](auto depth_c) __attribute__((always_inline)) {
+      BP8 crgb[PT];
+#pragma unroll
+      for (int t = 0; t < PT; ++t) crgb[t] = custom_piece(t, 0, 3);
+      static_for<PT>([&](auto t_c) { save_unit(t_c, p.gslot_out, crgb[decltype(t_c)::value], custom_piece(decltype(t_c)::value, 3, 1)); });   // for dW(fc_rgb), dW(fc_alpha)
+      // ---- d g = fc_rgb^T d rgb, masked by relu'(layers_dir.0 out) ----
+      stage_begin(q++);
+      run_stage48<F, NT / 2, 0, 1, 0, false, ST, 0, PH, 0, false>(pipe, none, [&](int t, int) { return crgb[t]; }, 0u, 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
+        emit_to(nt_c, t_c, acc, ba, p.gslot_dirout);
+      });
+      // ---- d feat = layers_dir.0[:, :W]^T d dirpre, masked by relu'(fc_feat out) ----
+      constexpr int P1 = (NT / 2) % kPhasePieces;
+      stage_begin(q++);
+      // (the stage's K is the first KH / 2 pieces of `ba`)
+      run_stage48<F, NT, KH / 2, 0, P1, false, ST, 0, PH, 0, false>(pipe, ba, no_pe, 0u, 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
+        emit_to(nt_c, t_c, acc, bb, p.gslot_feat);
+      });
+      // ---- d h = fc_feat^T d featpre + fc_alpha^T d alpha, masked by relu'(layers_xyz[D-2] out) ----
+      constexpr int P2 = (P1 + NT * (KH / 2)) % kPhasePieces;
+      stage_begin(q++);
+      // (the d sigma pieces are formed here, from the one live register per group: as arrays built at the top of the tile they
+      // are twelve registers - nine of them zeros - carried through two stages)
+      BP8 calpha[PT];
+#pragma unroll
+      for (int t = 0; t < PT; ++t) calpha[t] = custom_piece(t, 3, 1);
+      run_stage48<F, NT, KH, 1, P2, false, ST, 0, PH, 0, false>(pipe, bb, [&](int t, int) { return calpha[t]; }, 0u, 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
+        emit_to(nt_c, t_c, acc, ba, p.gslot_trunk0 + (p.D - 2) * KHU);
+      });
+      constexpr int PV = (P2 + NT * (KH + 1)) % kPhasePieces;
+      trunk(std::integral_constant<int, PV>{}, depth_c);
+    };
+    auto without_viewdirs = [&](auto depth_c) __attribute__((always_inline)) {
+      // ---- d h = fc_out^T d out, masked by relu'(layers_xyz[D-2] out) ----
+      BP8 cout[PT];
+#pragma unroll
+      for (int t = 0; t < PT; ++t) cout[t] = custom_piece(t, 0, 4);
+      static_for<PT>([&](auto t_c) { save_unit(t_c, p.gslot_out, cout[decltype(t_c)::value], BP8{}); });   // for dW(fc_out)
+      stage_begin(q++);
+      run_stage48<F, NT, 0, 1, 0, false, ST, 0, PH, 0, false>(pipe, none, [&](int t, int) { return cout[t]; }, 0u, 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
+        emit_to(nt_c, t_c, acc, ba, p.gslot_trunk0 + (p.D - 2) * KHU);
+      });
+      trunk(std::integral_constant<int, NT % kPhasePieces>{}, depth_c);
+    };
+    if constexpr (FIXED) {
+      if constexpr (VIEWC) with_viewdirs(std::integral_constant<int, DC>{});
+      else without_viewdirs(std::integral_constant<int, DC>{});
+    } else {
+      if (p.use_viewdirs) with_viewdirs(std::integral_constant<int, 0>{});
+      else without_viewdirs(std::integral_constant<int, 0>{});
+    }
+    g_slot ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+// ---- pack: nn.Linear tensors -> the transposed 16 x 32 A pieces of build_backward_layout48 ------------------------------
+__global__ void pack48_backward_kernel(NetLayout L, PackPtrs ptrs, char* __restrict__ out) {
+  __bf16* wout = reinterpret_cast<__bf16*>(out);
+  const long long n_elems = static_cast<long long>(L.total_pieces) * 64 * 8;
+  for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < n_elems;
+       idx += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int e = static_cast<int>(idx % 8);
+    const int lane = static_cast<int>((idx / 8) % 64);
+    const int piece = static_cast<int>(idx / 512);
+    const int i = lane & 15, g = lane >> 4;
+    float v = 0.0f;
+    int s = 0;
+    while (s + 1 < L.n_stages && L.st[s + 1].piece0 <= piece) ++s;
+    const StageDesc& st = L.st[s];
+    const int rel = piece - st.piece0;
+    if (rel < st.n_tiles * st.pieces_per_tile) {
+      // A[row][k] = W[k][row]: k runs over the forward layer's outputs in accumulator order (hidden pieces), then over one
+      // optional custom piece (lane group g, element e -> k = 8 g + e)
+      const int ts = rel / st.pieces_per_tile;
+      const int k = rel % st.pieces_per_tile;
+      const int kh = st.hidden_in / 32;
+      const int row = ts * 16 + i;
+      if (row < st.n_real) {
+        if (k < kh) {
+          v = ptrs.w[st.src][static_cast<long long>(g48_hidden_col(k, g, e)) * st.ld + row];
+        } else {
+          const int kc = 8 * g + e;
+          if (kc < st.custom_k) v = ptrs.w[st.src2 >= 0 ? st.src2 : st.src][static_cast<long long>(kc) * st.ld + row];
+        }
+      }
+    }
+    wout[idx] = static_cast<__bf16>(v);
+  }
+}
+
+// ---- s8-48 units -> plain (P, width) fp32 rows (tests and probes: dn_mlp_unpack with DN_PREC_BF16_S8) --------------------
+// which 0: e4m3 activations, 1: e5m2 gradients (x inv_scale).  kind 0: hidden vector, 1 / 2: xyz / view-direction panel,
+// 3: the custom unit (piece 0 elements 0-3 -> columns 0-3, piece 1 elements 0-3 -> columns 4-7: [d rgb . | d alpha . . .]).
+__global__ void unpack48_kernel(const char* __restrict__ buf, int units_per_group, int slot0, int n_units, int kind, int L,
+                                long long n_points, int which, float inv_scale, float* __restrict__ out, int ld_out, int col0) {
+  const long long groups = (n_points + 15) / 16;
+  const long long total = groups * n_units * 64 * 16;
+  for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+       idx += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int b = static_cast<int>(idx % 16);
+    const int lane = static_cast<int>((idx / 16) % 64);
+    const int u = static_cast<int>((idx / 1024) % n_units);
+    const long long G = idx / (1024LL * n_units);
+    const int g = lane >> 4, j = lane & 15;
+    const long long pt = G * 16 + j;
+    if (pt >= n_points) continue;
+    int col;
+    if (kind == 0) col = g48_hidden_col(2 * u + (b >> 3), g, b & 7);
+    else if (kind == 1) col = g48_pe_col(1, g, b, L);
+    else if (kind == 2) col = g < 2 ? g48_pe_col(2, g + 2 * (b >> 3), b & 7, L) : -1;
+    else col = (g == 0 && (b & 7) < 4) ? (b >> 3) * 4 + (b & 7) : -1;
+    if (col < 0) continue;
+    const char* src = buf + (((G >> 1) * units_per_group + slot0 + u) * 2 + (G & 1)) * kPieceBytes + lane * 16;
+    const int word = reinterpret_cast<const int*>(src)[b >> 2];
+    float v;
+    if (which == 0) v = (b & 3) == 0 ? __builtin_amdgcn_cvt_f32_fp8(word, 0) : (b & 3) == 1 ? __builtin_amdgcn_cvt_f32_fp8(word, 1)
+                        : (b & 3) == 2 ? __builtin_amdgcn_cvt_f32_fp8(word, 2) : __builtin_amdgcn_cvt_f32_fp8(word, 3);
+    else v = ((b & 3) == 0 ? __builtin_amdgcn_cvt_f32_bf8(word, 0) : (b & 3) == 1 ? __builtin_amdgcn_cvt_f32_bf8(word, 1)
+              : (b & 3) == 2 ? __builtin_amdgcn_cvt_f32_bf8(word, 2) : __builtin_amdgcn_cvt_f32_bf8(word, 3)) * inv_scale;
+    out[pt * ld_out + col0 + col] = v;
+  }
+}
+
+int unpack48_entry(const dn_mlp_desc* desc, int which, const void* native, int64_t n_points, int slot, int width, int kind, float* out,
+                   int ld_out, int col0, float grad_scale, hipStream_t stream) {
+  TrainLayout48 t;
+  build_train_layout48(*desc, &t);
+  const int per_group = which == 0 ? t.act_units : t.grad_units;
+  const int n_units = kind == 0 ? width / 64 : 1;
+  DN_REQUIRE((kind != 0 || width % 64 == 0) && slot >= 0 && slot + n_units <= per_group, "dn_mlp_unpack (8-bit layout): slot range outside the group's units");
+  const int L = kind == 1 ? desc->num_encoding_fn_xyz : desc->num_encoding_fn_dir;
+  hipLaunchKernelGGL(unpack48_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const char*>(native), per_group, slot, n_units, kind, L,
+                     static_cast<long long>(n_points), which, 1.0f / grad_scale, out, ld_out, col0);
+  return check_launch("dn_mlp_unpack");
+}
+
+int launch_pack48_backward(const dn_mlp_desc& d, const PackPtrs& ptrs, char* packed, hipStream_t stream) {
+  NetLayout L;
+  build_backward_layout48(d, &L);
+  hipLaunchKernelGGL(pack48_backward_kernel, dim3(512), dim3(256), 0, stream, L, ptrs, packed);
+  return check_launch("mlp_pack48_backward");
+}
+
+int launch_backward48(const dn_mlp_desc& d, Bwd48Params p, hipStream_t stream) {
+  NetLayout L;
+  build_backward_layout48(d, &L);
+  p.total_pieces = L.total_pieces;
+  p.n_tiles = static_cast<int>((p.n_points + kG48PointsPerWg - 1) / kG48PointsPerWg);
+  const size_t lds = static_cast<size_t>(kRingBytes) + kG48Waves * kBwd48WaveLds;
+  const int cus = device_cus();
+  const int grid = p.n_tiles < cus ? p.n_tiles : cus;
+  auto launch = [&](auto kern) -> int {
+    if (int rc = ensure_big_lds(reinterpret_cast<const void*>(kern))) return rc;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(kG48Waves * 64), lds, stream, p);
+    return check_launch("mlp_backward48");
+  };
+  const bool paper = d.hidden_size == 256 && d.num_layers == 8 && d.use_viewdirs;
+  const bool shipped = d.hidden_size == 128 && d.num_layers == 4 && d.use_viewdirs;
+  const bool fixed_ok = std::getenv("DEXNERF_G48_RUNTIME_SHAPE") == nullptr;
+#ifndef DN_T48_ONLY128
+  if (paper && fixed_ok) return launch(mlp_backward48_kernel<256, 8, 1>);
+#endif
+  if (shipped && fixed_ok) return launch(mlp_backward48_kernel<128, 4, 1>);
+#ifdef DN_T48_FIXED_ONLY   // developer hook: skip the run-time-shape instances (compile time)
+  set_error("mlp_backward48: built with the fixed-shape instances only");
+  return DN_E_UNSUPPORTED;
+#else
+  return d.hidden_size == 256 ? launch(mlp_backward48_kernel<256>) : launch(mlp_backward48_kernel<128>);
+#endif
+}
+
+}  // namespace dn
+
+using namespace dn;
+
+// The C entry points (dn_mlp_backward_data, dn_mlp_pack_backward, dn_mlp_train_sizes, ...) live in mlp_train.hip and dispatch here
+// for DN_PREC_BF16_S8.
+int dn::backward48_entry(const dn_mlp_desc* desc, const void* packed_bwd, const float* g_out, const void* masks, int64_t n_points,
+                         void* grads, float grad_scale, hipStream_t stream) {
+  TrainLayout48 t;
+  build_train_layout48(*desc, &t);
+  Bwd48Params p{};
+  p.packed = static_cast<const char*>(packed_bwd);
+  p.D = desc->num_layers;
+  p.use_viewdirs = desc->use_viewdirs;
+  p.g_out = g_out;
+  p.masks = static_cast<const char*>(masks);
+  p.mask_stages = t.mask_stages;
+  p.n_points = n_points;
+  p.grads = static_cast<char*>(grads);
+  p.grad_units = t.grad_units;
+  p.gslot_dirout = t.gslot_dirout; p.gslot_feat = t.gslot_feat; p.gslot_trunk0 = t.gslot_trunk0; p.gslot_layer1 = t.gslot_layer1;
+  p.gslot_out = t.gslot_out;
+  p.inv_scale = 1.0f / grad_scale;
+  p.clamp_hi = kE5m2Max / grad_scale;
+  p.clamp_lo = -p.clamp_hi;
+  return launch_backward48(*desc, p, stream);
+}

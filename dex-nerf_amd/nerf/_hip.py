@@ -27,7 +27,7 @@ EXPORTS = (
     "dn_mlp_backward_data", "dn_mlp_unpack", "dn_mlp_weight_grad", "dn_mlp_weight_grad_all",
     "dn_select_rays", "dn_select_rays_indirect", "dn_ndc_rays", "dn_dex_error_sweep", "dn_depth_error_image",
     "dn_render_train_workspace_bytes", "dn_render_rays_train", "dn_render_rays_backward",
-    "dn_set_s8_grad_scale", "dn_mlp_convert_saved_s8", "dn_mlp_pack_parts", "dn_fp16_range_guard",
+    "dn_set_s8_grad_scale", "dn_mlp_pack_parts", "dn_fp16_range_guard",
 )
 
 
@@ -84,7 +84,6 @@ def _declare(lib):
     lib.dn_mlp_weight_grad_all.argtypes = [POINTER(MlpDesc), c_int, vp, vp, c_int64, POINTER(c_void_p), POINTER(c_void_p), vp]
     lib.dn_set_s8_grad_scale.argtypes = [c_float]
     lib.dn_fp16_range_guard.argtypes = [POINTER(MlpDesc)]
-    lib.dn_mlp_convert_saved_s8.argtypes = [POINTER(MlpDesc), c_int, vp, c_int64, vp, vp]
     lib.dn_render_train_workspace_bytes.argtypes = [c_int64, c_int, c_int]
     lib.dn_render_train_workspace_bytes.restype = c_size_t
     lib.dn_render_rays_train.argtypes = [POINTER(MlpDesc), vp, POINTER(MlpDesc), vp, c_int, fp, c_int, c_int64, c_int, c_int,
@@ -109,7 +108,7 @@ def lib():
                 "g.build()'` (or `make -C dex-nerf_amd/csrc`).  The HIP path has no fallback.")
         handle = ctypes.CDLL(LIB_PATH)
         _declare(handle)
-        if handle.dn_abi_version() != 1:
+        if handle.dn_abi_version() != 2:
             raise RuntimeError("libdexnerf_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -71,9 +71,12 @@ def get_precision():
 
 
 def train_precision(packed):
-    """The precision code the TRAINING entry points get for this packed network (DN_PREC_BF16_S8 in the 'bf16-s8' mode).  A
-    forward records it with what it saves; the backward of those buffers uses the recorded code."""
-    return _hip.PREC_BF16_S8 if (_save8 and packed.precision == _hip.PREC_BF16) else packed.precision
+    """The precision code the TRAINING entry points get for this packed network: DN_PREC_BF16_S8 in the 'bf16-s8' mode where the
+    48-point training kernels cover the network (other shapes train in plain bf16).  A forward records it with what it saves; the
+    backward of those buffers uses the recorded code."""
+    if _save8 and packed.precision == _hip.PREC_BF16 and s8_supported(packed):
+        return _hip.PREC_BF16_S8
+    return packed.precision
 
 
 def set_s8_grad_scale(scale):
@@ -195,8 +198,8 @@ class PackedMLP:
         self.buffer = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.key = None          # parameter key the core stream (bias tiles + pieces: every kernel but one) was packed from
         self.key48 = None        # ... and the stream of the 48-point inference kernel: a training loop leaves it stale until a render
-        self.buffer_bwd = None   # transposed stream for the backward-data chain, packed on first training use
-        self.key_bwd = None
+        self.buffers_bwd = {}    # transposed streams for the backward-data chain, per training precision code (the 8-bit-saved-tensor
+        self.keys_bwd = {}       # mode runs the 48-point chain: another stream), packed on first training use
 
     def pack(self, weights, biases, parts=_hip.PACK_ALL):
         """weights/biases: lists of device tensors in the reference parameter order; parts: _hip.PACK_CORE | _hip.PACK_G48."""
@@ -214,21 +217,39 @@ class PackedMLP:
         left stale by the training entry points (FlexibleNeRFModel.packed(train=True)).  A caller that kept this object across
         optimizer steps instead of asking `model.packed()` again would render OLD weights without any error: refuse."""
         if self.key48 != self.key:
-            raise RuntimeError(f"{what}: the packed network's 48-point inference stream is older than its core stream (it was "
-                               "last packed by a training entry point) - obtain the packed network with model.packed() "
-                               "(no train=True) before rendering")
+            raise RuntimeError(f"{what}: the packed network's 48-point inference stream is older than its core stream or the other "
+                               "way round (it was last packed by a training entry point, which refreshes only the stream it reads) - "
+                               "obtain the packed network with model.packed() (no train=True) before rendering")
 
 
-def pack_backward(packed, weights):
-    """(Re)build the transposed weight stream used by dn_mlp_backward_data."""
-    if packed.buffer_bwd is None:
-        nbytes = lib().dn_mlp_backward_packed_bytes(ctypes.byref(packed.desc), packed.precision)
-        packed.buffer_bwd = torch.empty(nbytes, dtype=torch.uint8, device=packed.buffer.device)
+def pack_backward(packed, weights, prec=None):
+    """(Re)build the transposed weight stream dn_mlp_backward_data uses under training precision code `prec`."""
+    prec = train_precision(packed) if prec is None else prec
+    buf = packed.buffers_bwd.get(prec)
+    if buf is None:
+        nbytes = lib().dn_mlp_backward_packed_bytes(ctypes.byref(packed.desc), prec)
+        if nbytes == 0:
+            check(-1001, "dn_mlp_backward_packed_bytes")
+        buf = packed.buffers_bwd[prec] = torch.empty(nbytes, dtype=torch.uint8, device=packed.buffer.device)
     ws = [f32c(w.detach()) for w in weights]
     wp = (c_void_p * len(ws))(*[w.data_ptr() for w in ws])
-    check(lib().dn_mlp_pack_backward(ctypes.byref(packed.desc), packed.precision, wp, ptr(packed.buffer_bwd), stream()),
-          "dn_mlp_pack_backward")
+    check(lib().dn_mlp_pack_backward(ctypes.byref(packed.desc), prec, wp, ptr(buf), stream()), "dn_mlp_pack_backward")
     packed._keep_bwd = ws
+
+
+def ensure_backward_stream(model, packed, prec=None):
+    """The backward stream of `packed` for precision code `prec`, re-packed when the parameters changed (or under capture)."""
+    prec = train_precision(packed) if prec is None else prec
+    key = model.param_key()
+    if packed.keys_bwd.get(prec) != key or torch.cuda.is_current_stream_capturing():
+        pack_backward(packed, [m.weight for m in model.linear_modules()], prec)
+        packed.keys_bwd[prec] = key
+    return packed.buffers_bwd[prec]
+
+
+def s8_supported(packed):
+    """True when the 8-bit-saved-tensor training kernels (48-point geometry) cover this network."""
+    return lib().dn_mlp_backward_packed_bytes(ctypes.byref(packed.desc), _hip.PREC_BF16_S8) != 0
 
 
 def train_sizes(packed, n_points, s8=False, prec=None):
@@ -238,17 +259,6 @@ def train_sizes(packed, n_points, s8=False, prec=None):
     check(lib().dn_mlp_train_sizes(ctypes.byref(packed.desc), prec, n_points, ctypes.byref(a), ctypes.byref(m),
                                    ctypes.byref(g)), "dn_mlp_train_sizes")
     return a.value, m.value, g.value
-
-
-def convert_saved_s8(packed, which, native, n_points, grad_scale=None):
-    """bf16 saved activations (which = 0) / gradients (which = 1) -> the 8-bit unit layout of DN_PREC_BF16_S8 (experimental)."""
-    a8, _, g8 = train_sizes(packed, n_points, s8=True)
-    out = torch.empty(a8 if which == 0 else g8, dtype=torch.uint8, device=native.device)
-    if grad_scale is not None:
-        check(lib().dn_set_s8_grad_scale(float(grad_scale)), "dn_set_s8_grad_scale")
-    check(lib().dn_mlp_convert_saved_s8(ctypes.byref(packed.desc), which, ptr(native), n_points, ptr(out), stream()),
-          "dn_mlp_convert_saved_s8")
-    return out
 
 
 def run_network_train(packed, pts, viewdirs, samples_per_ray, rays=None, z_vals=None, prec=None):
@@ -286,14 +296,15 @@ def mlp_backward_data(packed, g_out, masks, n_points, prec=None):
     prec = packed.precision if prec is None else prec
     _, _, g_bytes = train_sizes(packed, n_points, prec=prec)
     grads = torch.empty(g_bytes, dtype=torch.uint8, device=g_out.device)
-    check(lib().dn_mlp_backward_data(ctypes.byref(packed.desc), prec, ptr(packed.buffer_bwd), ptr(g_out),
+    check(lib().dn_mlp_backward_data(ctypes.byref(packed.desc), prec, ptr(packed.buffers_bwd[prec]), ptr(g_out),
                                      ptr(masks), n_points, ptr(grads), stream()), "dn_mlp_backward_data")
     return grads
 
 
-def mlp_unpack(packed, which, native, n_points, slot, width, kind, out, col0=0):
-    """native pieces -> out[:, col0:col0+width_or_pe_dim] (plain fp32 rows)."""
-    check(lib().dn_mlp_unpack(ctypes.byref(packed.desc), packed.precision, which, ptr(native), n_points, slot, width, kind,
+def mlp_unpack(packed, which, native, n_points, slot, width, kind, out, col0=0, prec=None):
+    """native pieces -> out[:, col0:col0+width_or_pe_dim] (plain fp32 rows).  prec = PREC_BF16_S8: the 8-bit units of the
+    48-point training kernels (slot in units of 64 features per 16-point group; kind 3 = the custom output-gradient unit)."""
+    check(lib().dn_mlp_unpack(ctypes.byref(packed.desc), packed.precision if prec is None else prec, which, ptr(native), n_points, slot, width, kind,
                               ptr(out), out.shape[1], col0, stream()), "dn_mlp_unpack")
     return out
 
@@ -501,7 +512,7 @@ def render_nonfinite_count(ws=None):
 
 
 # ---- predict_and_render_radiance under autograd: one C call forward, one (or two halves) backward ----------------------
-def render_rays_train(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, noise_std, white, m_thres, draws=None):
+def render_rays_train(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, noise_std, white, m_thres, draws=None, prec=None):
     """dn_render_rays_train: the training forward of a whole ray chunk.  Returns (maps, saved): maps = (rgb_c, depth_c, acc_c,
     rgb_f, depth_f, acc_f, dex), saved = what dn_render_rays_backward needs (workspace, per-network act / masks, the draws)."""
     rays = f32c(rays)
@@ -516,7 +527,7 @@ def render_rays_train(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, n
     def new(*shape):
         return torch.empty(shape, dtype=torch.float32, device=dev)
 
-    prec = train_precision(packed_c)
+    prec = train_precision(packed_c) if prec is None else prec
 
     def bufs(packed, n_points):
         a, m, _ = train_sizes(packed, n_points, prec=prec)
@@ -562,8 +573,8 @@ def render_rays_backward(packed_c, packed_f, saved, g_c, g_f, views_c, views_f, 
     wf, bf = arrays(views_f if (fine and nets & 2) else None)
     gs = [None if g is None else f32c(g) for g in tuple(g_c) + tuple(g_f)]
     check(lib().dn_render_rays_backward(
-        ctypes.byref(packed_c.desc), ptr(packed_c.buffer_bwd),
-        ctypes.byref(packed_f.desc) if fine else None, ptr(packed_f.buffer_bwd) if fine else None, prec,
+        ctypes.byref(packed_c.desc), ptr(packed_c.buffers_bwd[prec]),
+        ctypes.byref(packed_f.desc) if fine else None, ptr(packed_f.buffers_bwd[prec]) if fine else None, prec,
         ptr(saved["rays"]), saved["rays"].shape[1], n, nc, nf, saved["noise_std"], int(saved["white"]),
         ptr(saved["noise_c"]), ptr(saved["noise_f"]), ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]), ptr(gs[5]),
         ptr(saved["ws"]), ptr(saved["act_c"]), ptr(saved["masks_c"]), ptr(grads_c), ptr(saved["act_f"]), ptr(saved["masks_f"]),

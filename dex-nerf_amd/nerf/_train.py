@@ -60,12 +60,8 @@ class FusedNetFn(torch.autograd.Function):
             raise RuntimeError("FusedNetFn differentiates w.r.t. the model parameters only; points / rays / view directions that "
                                "require grad must go through the nn.Linear composition (run_network does that by itself)")
         pk = model.packed(log_xyz, log_dir, train=True)
-        mods = model.linear_modules()
-        key = model.param_key()
-        if pk.key_bwd != key or torch.cuda.is_current_stream_capturing():
-            _ops.pack_backward(pk, [m.weight for m in mods])
-            pk.key_bwd = key
         prec = _ops.train_precision(pk)
+        _ops.ensure_backward_stream(model, pk, prec)
         if samples_per_ray is None:
             out, act, masks = _ops.run_network_train(pk, None, None, None, rays=pts, z_vals=viewdirs, prec=prec)
         else:
@@ -153,14 +149,13 @@ class RenderRaysTrainFn(torch.autograd.Function):
         num_coarse, num_fine, lindisp, noise_std, white = cfg
         pc = model_c.packed(*logs, train=True)
         pf = model_f.packed(*logs, train=True) if model_f is not None else None
+        prec = _ops.train_precision(pc)
+        if pf is not None and _ops.train_precision(pf) != prec:
+            prec = pc.precision   # one of the two networks is outside the 8-bit-saved-tensor kernels: both train in plain bf16
         for model, pk in ((model_c, pc), (model_f, pf)):
-            if model is None:
-                continue
-            key = model.param_key()
-            if pk.key_bwd != key or torch.cuda.is_current_stream_capturing():
-                _ops.pack_backward(pk, [m.weight for m in model.linear_modules()])
-                pk.key_bwd = key
-        maps, saved = _ops.render_rays_train(pc, pf, rays, num_coarse, num_fine, lindisp, noise_std, white, thres, draws)
+            if model is not None:
+                _ops.ensure_backward_stream(model, pk, prec)
+        maps, saved = _ops.render_rays_train(pc, pf, rays, num_coarse, num_fine, lindisp, noise_std, white, thres, draws, prec=prec)
         ctx.models, ctx.packed, ctx.saved = (model_c, model_f), (pc, pf), saved
         ctx.sinks = tuple(getattr(m, "_grad_sink", None) if m is not None else None for m in (model_c, model_f))
         for sink in ctx.sinks:

@@ -85,9 +85,9 @@ class FlexibleNeRFModel(torch.nn.Module):
                     log_sampling_xyz=log_sampling_xyz, log_sampling_dir=log_sampling_dir)
 
     def packed(self, log_sampling_xyz=True, log_sampling_dir=True, train=False, precision=None):
-        """MFMA fragment stream for the current parameters (re-packed when any parameter changed).  `train=True` (the training
-        entry points: they never run the 48-point inference kernel) leaves that kernel's own stream stale; the next caller
-        without it - any render - brings it up to date.
+        """MFMA fragment streams for the current parameters (re-packed when any parameter changed).  `train=True` (the training
+        entry points) refreshes only the stream the training forward reads - the core one, or the 48-point kernel's in the
+        8-bit-saved-tensor mode - and leaves the other stale; the next caller without it - any render - brings both up to date.
 
         "Changed" = a new storage, a bumped tensor version (every ordinary in-place op), or ANY optimizer step since the
         last pack: fused optimizers (`Adam(fused=True)`) update parameters without bumping their versions."""
@@ -103,10 +103,16 @@ class FlexibleNeRFModel(torch.nn.Module):
         # under stream capture always (re)pack: a captured graph must contain the pack of the weights it runs on, whatever
         # the host-side cache believes at capture time
         capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        # a training entry point reads ONE of the two streams: the 48-point one in the 8-bit-saved-tensor mode (its forward is the
+        # 48-point kernel), the core one otherwise; a render may read either
+        want_core = want_48 = True
+        if train:
+            want_48 = _ops.train_precision(pk) == _hip.PREC_BF16_S8
+            want_core = not want_48
         parts = 0
-        if pk.key != key or capturing:
+        if want_core and (pk.key != key or capturing):
             parts |= _hip.PACK_CORE
-        if not train and (pk.key48 != key or capturing):
+        if want_48 and (pk.key48 != key or capturing):
             parts |= _hip.PACK_G48
         if parts:
             pk.pack([m.weight for m in mods], [m.bias for m in mods], parts)

@@ -26,7 +26,7 @@ with tempfile.TemporaryDirectory(dir=os.path.join(os.path.dirname(os.path.abspat
             blk = ".agpr_count:" + blk
             get = lambda k: (re.search(rf"\.{k}:\s*(\S+)", blk) or [None, "?"])[1]
             name = subprocess.check_output(["c++filt", get("name")], text=True).strip()
-            rows.append((name, get("vgpr_count"), get("agpr_count"), get("sgpr_count"), get("vgpr_spill_count"),
+            rows.append((name, get("vgpr_count"), get("agpr_count"), get("sgpr_count"), get("vgpr_spill_count") + "/" + get("sgpr_spill_count"),
                          get("private_segment_fixed_size"), get("group_segment_fixed_size"), get("max_flat_workgroup_size")))
     print(f"{'vgpr':>5} {'agpr':>5} {'sgpr':>5} {'spill':>5} {'scratch':>7} {'lds':>6} {'wg':>5}  kernel")
     for r in rows:

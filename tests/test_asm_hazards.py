@@ -7,7 +7,7 @@ hazard recognizer and waitcnt insertion cannot see - is checked in the instructi
     DESIGN.md section 4.6);
   * M0 written one instruction + nop before the LDS-DMA that reads it;
   * no VALU write to a > 8-byte store's data registers in the following wait state (the round-1 data corruption);
-  * the explicit LDS read pipeline of mlp_forward48_kernel: nothing names a fragment register between its ds_read and the
+  * the explicit LDS read pipeline of mlp_forward48_kernel / mlp_backward48_kernel: nothing names a fragment register between its ds_read and the
     counted s_waitcnt that retires it (the compiler sees the fragment as an ordinary value from the read-asm on; a phi copy at
     a control-flow merge once read them early - caught on the GPU by the geometry test, now caught here first).
 """
@@ -65,7 +65,7 @@ def test_wide_store_data_registers_are_not_rewritten_at_once(kernels):
 def test_explicit_lds_read_pipeline_is_not_touched_in_flight(kernels):
     seen = 0
     for name, ins in kernels.items():
-        if "mlp_forward48_kernel" not in name:
+        if "mlp_forward48_kernel" not in name and "mlp_backward48_kernel" not in name:
             continue
         seen += 1
         bad = codeobj.lds_read_violations(ins)
@@ -73,7 +73,7 @@ def test_explicit_lds_read_pipeline_is_not_touched_in_flight(kernels):
         # the pipeline is really the explicit one: counted waits dominate, the hot loop has no lgkmcnt(0) after a fresh read
         counted = sum(1 for line in ins if line.startswith("s_waitcnt lgkmcnt(1)") or line.startswith("s_waitcnt lgkmcnt(2)"))
         assert counted > 150, (name, counted)
-    assert seen == 8
+    assert seen == 16   # forward: 2 widths x {fixed, run-time shape} x {bf16, fp16, bf16 training}; backward: 2 widths x {fixed, run-time}
 
 
 def test_the_checkers_catch_planted_hazards():

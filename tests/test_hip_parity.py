@@ -1532,37 +1532,96 @@ def test_bench_multi_gpu_leg_rehearsal_two_ranks_one_gpu(dev):
 
 
 # ---- 8-bit saved tensors (DN_PREC_BF16_S8, nerf.set_precision("bf16-s8")) -----------------------------------------------------
-@pytest.mark.parametrize("depth,width,viewdirs", [(8, 256, True), (4, 128, True), (8, 256, False), (5, 128, False)])
-def test_s8_saved_tensors_are_the_bf16_ones_rounded(dev, depth, width, viewdirs):
-    """The training forward / backward-data kernels in DN_PREC_BF16_S8 compute exactly what the bf16 ones do (same radiance field,
-    same ReLU masks) and store what they save for the weight-gradient kernel at 8 bits: bit for bit the bf16 buffers put through
-    dn_mlp_convert_saved_s8 (e4m3 activations; e5m2 of gradient x 65536, saturated) at half the bytes.  Ragged point count."""
+@pytest.mark.parametrize("depth,width,viewdirs,skip", [(8, 256, True, 4), (4, 128, True, 4), (8, 256, False, 3), (5, 128, False, 2), (3, 256, True, 2)])
+def test_s8_training_kernels_in_the_48_point_geometry(dev, depth, width, viewdirs, skip):
+    """DN_PREC_BF16_S8 = the training forward and the backward-data chain on v_mfma_f32_16x16x32_bf16, 48 points per wave (fixed-shape
+    instances: D8/W256 and 4x128 with view directions; run-time-shape ones: the rest), saved tensors at 8 bits in the s8-48 layout.
+      * the training forward's radiance field equals the bf16 48-point INFERENCE kernel's bit for bit;
+      * every saved activation (unpacked with dn_mlp_unpack) is the bf16 32-point training kernel's saved activation rounded to
+        e4m3 - same products, another fp32 summation grouping, so compared to 3 mantissa bits: |a8 - a16| <= 0.07 |a16| + 2^-8
+        on >= 99.9 % of the elements - and both encodings likewise;
+      * every saved layer gradient is the 32-point bf16 backward chain's (same upstream gradient; the masks of each geometry's
+        own forward) to e5m2's 2 mantissa bits: |g8 - g16| <= 0.14 |g16| + 1e-9 on >= 99 %, cosine >= 0.995 per stage;
+      * the fp8-MFMA weight-gradient kernel on the 8-bit buffers against the bf16 kernel on the bf16 ones: cosine > 0.99 per
+        tensor.  Ragged point count (37 x 53 points: partial 384-point tile, partial 32-point record, partial 16-point group)."""
     import nerf
-    from nerf import _hip, _ops
+    from nerf import _hip, _ops, _train
     nerf.set_precision("bf16")
     try:
         torch.manual_seed(3)
-        m = nerf.models.FlexibleNeRFModel(num_layers=depth, hidden_size=width, skip_connect_every=3, num_encoding_fn_xyz=10,
+        m = nerf.models.FlexibleNeRFModel(num_layers=depth, hidden_size=width, skip_connect_every=skip, num_encoding_fn_xyz=10,
                                           num_encoding_fn_dir=4, use_viewdirs=viewdirs).to(dev)
         pk = m.packed()
-        _ops.pack_backward(pk, [x.weight for x in m.linear_modules()])
+        weights = [x.weight for x in m.linear_modules()]
+        _ops.pack_backward(pk, weights, _hip.PREC_BF16)
+        _ops.pack_backward(pk, weights, _hip.PREC_BF16_S8)
+        assert _ops.s8_supported(pk)
         n_rays, s = 37, 53
         n = n_rays * s
         pts = torch.rand(n, 3, device=dev) * 2 - 1
         vd = torch.nn.functional.normalize(torch.randn(n_rays, 3, device=dev), dim=-1) if viewdirs else None
         g_out = torch.randn(n, 4, device=dev) * 1e-4
-        out, act, masks = _ops.run_network_train(pk, pts, vd, s)
+        out, act, masks = _ops.run_network_train(pk, pts, vd, s, prec=_hip.PREC_BF16)
         out8, act8, masks8 = _ops.run_network_train(pk, pts, vd, s, prec=_hip.PREC_BF16_S8)
-        assert torch.equal(out, out8) and torch.equal(masks, masks8)
-        assert act8.numel() * 2 <= act.numel() + act.numel() // 8 and act8.numel() < act.numel()
-        assert torch.equal(act8, _ops.convert_saved_s8(pk, 0, act, n))
-        grads = _ops.mlp_backward_data(pk, g_out, masks, n)
+        with torch.no_grad():
+            inference = _ops.run_network_pts(pk, pts, vd, s)
+        assert torch.equal(out8, inference)
+        assert act8.numel() < 0.62 * act.numel()
+        grads = _ops.mlp_backward_data(pk, g_out, masks, n, prec=_hip.PREC_BF16)
         grads8 = _ops.mlp_backward_data(pk, g_out, masks8, n, prec=_hip.PREC_BF16_S8)
-        assert grads8.numel() < grads.numel()
-        assert torch.equal(grads8, _ops.convert_saved_s8(pk, 1, grads, n))
-        # and the fp8-MFMA weight-gradient kernel on them against the bf16 kernel on the bf16 buffers
+        assert grads8.numel() < 0.62 * grads.numel()
+        # stage by stage through the unpackers of the two layouts
+        slots, gslots, kh = _train._slots(m, _hip.PREC_BF16)            # 32-point layout: slots in 16-deep pieces
+        d, w = depth, width
+        khu = w // 64                                                    # s8-48 layout: slots in 64-feature units per 16-point group
+        s8 = {"xyz": 0, "dir": 1, "layer1": 1 + (1 if viewdirs else 0)}
+        s8["trunk0"] = s8["layer1"] + khu
+        s8["feat"] = s8["trunk0"] + (d - 1) * khu
+        s8["dirout"] = s8["feat"] + (khu if viewdirs else 0)
+        g8 = {"dirout": 0, "feat": (w // 128) if viewdirs else 0}
+        g8["trunk0"] = g8["feat"] + (khu if viewdirs else 0)
+        g8["layer1"] = g8["trunk0"] + (d - 1) * khu
+        g8["out"] = g8["layer1"] + khu
+
+        def rows16(which, buf, slot, width_, kind=0):
+            return C(_ops.mlp_unpack(pk, which, buf, n, slot, width_, kind, torch.zeros((n, width_), dtype=torch.float32, device=dev))).astype(np.float64)
+
+        def rows8(which, buf, slot, width_, kind=0, cols=None):
+            o = torch.zeros((n, cols or width_), dtype=torch.float32, device=dev)
+            return C(_ops.mlp_unpack(pk, which, buf, n, slot, width_, kind, o, prec=_hip.PREC_BF16_S8)).astype(np.float64)
+
+        def close_act(a8, a16, what):
+            ok = np.abs(a8 - a16) <= 0.07 * np.abs(a16) + 2.0 ** -8
+            assert ok.mean() >= 0.999, (what, ok.mean(), np.abs(a8 - a16).max())
+
+        def close_grad(a8, a16, what):
+            ok = np.abs(a8 - a16) <= 0.14 * np.abs(a16) + 1e-9
+            cos = float((a8 * a16).sum() / max(np.linalg.norm(a8) * np.linalg.norm(a16), 1e-300))
+            assert ok.mean() >= 0.99 and cos >= 0.995, (what, ok.mean(), cos)
+
+        close_act(rows8(0, act8, s8["xyz"], m.dim_xyz, 1), rows16(0, act, slots["xyz"], m.dim_xyz, 1), "xyz encoding")
+        if viewdirs:
+            close_act(rows8(0, act8, s8["dir"], m.dim_dir, 2), rows16(0, act, slots["dir"], m.dim_dir, 2), "view-direction encoding")
+        close_act(rows8(0, act8, s8["layer1"], w), rows16(0, act, slots["layer1"], w), "layer1")
+        close_grad(rows8(1, grads8, g8["layer1"], w), rows16(1, grads, gslots["layer1"], w), "d layer1")
+        for i in range(d - 1):
+            close_act(rows8(0, act8, s8["trunk0"] + i * khu, w), rows16(0, act, slots["trunk0"] + i * kh, w), f"layers_xyz[{i}]")
+            close_grad(rows8(1, grads8, g8["trunk0"] + i * khu, w), rows16(1, grads, gslots["trunk0"] + i * kh, w), f"d layers_xyz[{i}]")
+        if viewdirs:
+            close_act(rows8(0, act8, s8["feat"], w), rows16(0, act, slots["feat"], w), "fc_feat")
+            close_grad(rows8(1, grads8, g8["feat"], w), rows16(1, grads, gslots["feat"], w), "d fc_feat")
+            # (the 64-feature units of a W = 128 net's 64-wide layers_dir.0 output: one unit)
+            close_act(rows8(0, act8, s8["dirout"], max(w // 2, 64))[:, : w // 2], rows16(0, act, slots["dirout"], w // 2), "layers_dir.0")
+            close_grad(rows8(1, grads8, g8["dirout"], max(w // 2, 64))[:, : w // 2], rows16(1, grads, gslots["dirout"], w // 2), "d layers_dir.0")
+        custom = rows8(1, grads8, g8["out"], 8, 3, cols=8)
+        want = C(g_out).astype(np.float64)
+        if viewdirs:
+            close_grad(custom[:, [0, 1, 2, 4]], want, "custom output-gradient unit")
+        else:
+            close_grad(custom[:, :4], want, "custom output-gradient unit")
+        # the fp8-MFMA weight-gradient kernel on the 8-bit buffers against the bf16 kernel on the bf16 buffers
         shapes = [tuple(x.weight.shape) for x in m.linear_modules()]
-        ref = _ops.mlp_weight_grad_all(pk, act, grads, n, shapes)
+        ref = _ops.mlp_weight_grad_all(pk, act, grads, n, shapes, prec=_hip.PREC_BF16)
         got = _ops.mlp_weight_grad_all(pk, act8, grads8, n, shapes, prec=_hip.PREC_BF16_S8)
         for (w16, b16), (w8, b8), mod in zip(ref, got, m.linear_modules()):
             for a, b in ((w8, w16), (b8, b16)):
@@ -1573,9 +1632,40 @@ def test_s8_saved_tensors_are_the_bf16_ones_rounded(dev, depth, width, viewdirs)
         nerf.set_precision("fp32")
 
 
+def test_s8_saturates_instead_of_overflowing(dev):
+    """The 8-bit conversions do not saturate in hardware (an e4m3 overflow converts to NaN, an e5m2 one to infinity: measured,
+    scripts/micro/cvt_scale_probe.hip) - the kernels clamp first.  A network driven to activations beyond 448 and gradients beyond
+    57344 / scale must still give finite weight gradients."""
+    import nerf
+    from nerf import _hip, _ops
+    nerf.set_precision("bf16")
+    try:
+        torch.manual_seed(5)
+        m = nerf.models.FlexibleNeRFModel(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10,
+                                          num_encoding_fn_dir=4, use_viewdirs=True).to(dev)
+        with torch.no_grad():
+            m.layers_xyz[0].weight.mul_(3.0e3)        # activations of the order of 1e3 - 1e4 (> 448)
+        pk = m.packed()
+        _ops.pack_backward(pk, [x.weight for x in m.linear_modules()], _hip.PREC_BF16_S8)
+        n_rays, s = 24, 40
+        n = n_rays * s
+        pts = torch.rand(n, 3, device=dev) * 2 - 1
+        vd = torch.nn.functional.normalize(torch.randn(n_rays, 3, device=dev), dim=-1)
+        out8, act8, masks8 = _ops.run_network_train(pk, pts, vd, s, prec=_hip.PREC_BF16_S8)
+        big = _ops.mlp_unpack(pk, 0, act8, n, 2 + 128 // 64, 128, 0, torch.zeros((n, 128), dtype=torch.float32, device=dev), prec=_hip.PREC_BF16_S8)
+        assert bool(torch.isfinite(big).all()) and float(big.max()) == 448.0      # layers_xyz[0]'s output: saturated, not NaN
+        g_out = torch.randn(n, 4, device=dev) * 10.0                               # x 65536 >> 57344
+        grads8 = _ops.mlp_backward_data(pk, g_out, masks8, n, prec=_hip.PREC_BF16_S8)
+        shapes = [tuple(x.weight.shape) for x in m.linear_modules()]
+        for d_w, d_b in _ops.mlp_weight_grad_all(pk, act8, grads8, n, shapes, prec=_hip.PREC_BF16_S8):
+            assert bool(torch.isfinite(d_w).all()) and bool(torch.isfinite(d_b).all())
+    finally:
+        nerf.set_precision("fp32")
+
+
 def test_s8_training_step_gradients(golden, dev):
     """One whole training step (both D8/W256 nets, 64 + 128 samples, perturbed) in the three training modes: the 'bf16-s8' mode's
-    forward is the bf16 mode's bit for bit (same loss), and its parameter gradients are as close to the fp32 mode's as the bf16
+    forward agrees with the bf16 mode's to the accumulation order (loss within 2e-3), and its parameter gradients are as close to the fp32 mode's as the bf16
     mode's are (cosine per tensor; the gate: within 5e-3 of the bf16 mode's cosine against fp32 and >= 0.93 - layer1 of a bf16
     step sits at 0.955 on these rays - and >= 0.998 against the bf16 mode's own gradient)."""
     import nerf
@@ -1606,7 +1696,8 @@ def test_s8_training_step_gradients(golden, dev):
             res[prec] = (float(loss.detach()), [C(p.grad).astype(np.float64).reshape(-1) for m in models for p in m.parameters()])
     finally:
         nerf.set_precision("fp32")
-    assert res["bf16-s8"][0] == res["bf16"][0]
+    # (the 8-bit mode's forward is the 48-point kernel, the bf16 mode's the 32-point one: same products, another fp32 grouping)
+    assert abs(res["bf16-s8"][0] - res["bf16"][0]) < 2e-3 * abs(res["bf16"][0])
     assert abs(res["bf16"][0] - res["fp32"][0]) < 5e-3 * abs(res["fp32"][0])
 
     def cos(a, b):

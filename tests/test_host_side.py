@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(hiplib):
     raw = ctypes.CDLL(_hip.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert hiplib.dn_abi_version() == 1
+    assert hiplib.dn_abi_version() == 2
 
 
 def test_argument_validation_needs_no_gpu(hiplib):
@@ -75,7 +75,21 @@ def test_argument_validation_needs_no_gpu(hiplib):
         sizes[prec] = (a.value, m.value, g.value)
     a16, m16, g16 = sizes[_hip.PREC_BF16]
     a8, m8, g8 = sizes[_hip.PREC_BF16_S8]
-    assert m8 == m16 and a16 == 2 * a8 and g8 * 2 - g16 in (0, 32 * 1024)   # (1000 points = 32 tiles of 32; an odd piece count pads one unit per tile)
+    # the 8-bit mode runs the 48-point geometry (mlp_geo48.h): 1 KiB units of 64 features per 16-point group, two groups per
+    # 32-point record, whole 384-point workgroup tiles (1000 points = 3 tiles = 36 records); two 1 KiB mask words per wave
+    # tile and masked stage
+    dd, ww, v = d.num_layers, d.hidden_size, int(d.use_viewdirs)
+    khu = ww // 64
+    act_units = 1 + v + khu * (1 + (dd - 1) + v) + (ww // 128) * v
+    grad_units = (ww // 128) * v + khu * v + (dd - 1) * khu + khu + 1
+    assert a8 == 36 * 2 * act_units * 1024 and g8 == 36 * 2 * grad_units * 1024 and m8 == 3 * 8 * (dd - 1 + 2 * v) * 2 * 1024
+    assert a8 < 0.6 * a16 and g8 < 0.6 * g16   # (half the bytes per point; 36 records against the 32-point kernels' 32 tiles)
+    # networks outside the 48-point kernels are refused (and train in plain bf16)
+    d_deep = _hip.MlpDesc(**{k: getattr(d, k) for k, _ in d._fields_})
+    d_deep.num_layers = 12
+    assert hiplib.dn_mlp_train_sizes(ctypes.byref(d_deep), _hip.PREC_BF16_S8, 1000, ctypes.byref(a), ctypes.byref(m), ctypes.byref(g)) == -1001
+    assert hiplib.dn_mlp_backward_packed_bytes(ctypes.byref(d_deep), _hip.PREC_BF16_S8) == 0 and hiplib.dn_mlp_backward_packed_bytes(ctypes.byref(d), _hip.PREC_BF16_S8) > 0
+    assert hiplib.dn_fp16_range_guard(ctypes.byref(d)) in (0, 1)
     assert hiplib.dn_set_s8_grad_scale(3.0) == -1000 and b"power of two" in hiplib.dn_last_error()
     assert hiplib.dn_set_s8_grad_scale(65536.0) == 0
     with pytest.raises(RuntimeError):

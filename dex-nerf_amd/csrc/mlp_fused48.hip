@@ -261,14 +261,16 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     auto mask_tail = [&](auto nt_c, auto t_c, const auto& bo) {
       if constexpr (SAVE != 0) {
         constexpr int nt = decltype(nt_c)::value, t = decltype(t_c)::value;
-        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-        const u16x2 one = {1, 1};
         const u32x4 w = __builtin_bit_cast(u32x4, bo[nt / 2]);
+        const unsigned ones = 0x00010001u;
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           // (through a named scalar: __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index - hipcc 7.2)
           const unsigned pair = w[(nt & 1) * 2 + d];
-          const unsigned m = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, pair), one));
+          // non-zero <=> the unit is active: min(x, 1) on both 16-bit halves.  As an instruction: written with the vector builtins
+          // hipcc lowers it to two compares, two selects and a v_perm_b32
+          unsigned m;
+          asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(pair), "s"(ones));
           // (opaque: as plain ORs the optimiser may reassociate the stage's chain and keep every m alive to its end)
           unsigned mw = maskw[t][nt >> 3];   // (asm operands do not capture: name a local)
           asm volatile("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(mw) : "v"(m), "n"((nt & 7) * 2 + d));

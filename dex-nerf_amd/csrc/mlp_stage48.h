@@ -157,11 +157,13 @@ __device__ __forceinline__ void emit48(const f32x4& acc, BO& bo) {
   for (int d = 0; d < 2; ++d) {
     f32x2 f = {acc[2 * d], acc[2 * d + 1]};
     if constexpr (CLAMP) {
-      if constexpr (RELU) { f[0] = fminf(f[0], kE4m3Max); f[1] = fminf(f[1], kE4m3Max); }
-      else { f[0] = __builtin_amdgcn_fmed3f(f[0], -kE4m3Max, kE4m3Max); f[1] = __builtin_amdgcn_fmed3f(f[1], -kE4m3Max, kE4m3Max); }
+      // one v_med3_f32 per element: ReLU and the upper limit at once (fminf / fmaxf each cost a canonicalising v_max_f32 more)
+      constexpr float lo = RELU ? 0.0f : -kE4m3Max;
+      f[0] = __builtin_amdgcn_fmed3f(f[0], lo, kE4m3Max);
+      f[1] = __builtin_amdgcn_fmed3f(f[1], lo, kE4m3Max);
     }
     e16x2 v = __builtin_convertvector(f, e16x2);  // one packed convert
-    if constexpr (RELU) {  // a negative bf16 / fp16 is a negative int16 (mlp_device.h make_piece)
+    if constexpr (RELU && !CLAMP) {  // a negative bf16 / fp16 is a negative int16 (mlp_device.h make_piece)
       s16x2 bits = __builtin_bit_cast(s16x2, v);
       const s16x2 zero = {0, 0};
       bits = __builtin_elementwise_max(bits, zero);

@@ -4,7 +4,7 @@ import csv, glob, json, sys
 from collections import defaultdict
 
 mode = sys.argv[1]
-KERNELS = ("mlp_forward_kernel", "mlp_backward_kernel", "weight_grad_batch_kernel")
+KERNELS = ("mlp_forward_kernel", "mlp_backward_kernel", "mlp_forward48_kernel", "mlp_backward48_kernel", "weight_grad_batch_kernel")
 out = {"mode": mode, "kernels": {}}
 for name in ("mfma", "sqA", "sqB"):
     cc = glob.glob(f"gpurun_out/pmc_train_{mode}_{name}/*/*counter_collection.csv")

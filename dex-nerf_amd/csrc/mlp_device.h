@@ -686,6 +686,23 @@ __device__ __forceinline__ void store16_uniform_at(const char* base, unsigned by
                : [tmp] "=&v"(tmp) : [voff] "v"(voff), [off] "s"(off), [data] "v"(data), [sbase] "s"(b) : "memory");
 }
 
+// The unit store of the s8-48 layout (mlp_geo48.h): as store16_uniform_at, with the lane's row inside the 1 KiB unit swizzled -
+// lane (g = lane / 16, j = lane % 16) writes row g * 16 + (j ^ 8 (g & 1)): the odd lane groups keep their first eight points in
+// the upper 128 bytes of their 256, so that the weight-gradient kernel's two 16-lane read groups (an even and an odd lane group,
+// eight points each) fall on different halves of the 64 LDS banks (PMC on the unswizzled layout: one conflict cycle per LDS cycle).
+template <class V>
+__device__ __forceinline__ void store16_unit48(const char* base, unsigned byte_off, unsigned lane16, const V& val) {
+  static_assert(sizeof(V) == 16, "one dwordx4 per lane");
+  const char* b = base;
+  const unsigned off = byte_off;
+  const unsigned voff = lane16;
+  const f32x4 data = __builtin_bit_cast(f32x4, val);
+  unsigned tmp;
+  asm volatile("v_and_b32 %[tmp], 0x100, %[voff]\n\tv_lshrrev_b32 %[tmp], 1, %[tmp]\n\tv_xor_b32 %[tmp], %[tmp], %[voff]\n\tv_add_u32 %[tmp], %[off], %[tmp]\n\t"
+               "s_nop 4\n\tglobal_store_dwordx4 %[tmp], %[data], %[sbase]" DN_STORE_POLICY "\n\ts_nop 1"
+               : [tmp] "=&v"(tmp) : [voff] "v"(voff), [off] "s"(off), [data] "v"(data), [sbase] "s"(b) : "memory");
+}
+
 // ---- 8-bit saved tensors (DN_PREC_BF16_S8): a bf16 B piece (8 values per lane) -> 8 bytes --------------------------
 // GRAD = false: e4m3 (activations, O(1)), saturated at +-448 (OCP e4m3 has no infinity: an unclamped overflow converts to NaN,
 // and one NaN activation poisons a whole layer's weight gradient); GRAD = true: e5m2 of value * scale, saturated at +-57344

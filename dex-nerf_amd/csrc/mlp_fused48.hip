@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
             return __builtin_bit_cast(unsigned, r);
           };
           const u32x4_ a = __builtin_bit_cast(u32x4_, pk[0]), b = __builtin_bit_cast(u32x4_, pk[1]);
-          store16_uniform_at(act_grp[t], static_cast<unsigned>(p.slot_xyz) * (2 * kPieceBytes), static_cast<unsigned>(ln) * 16u,
+          store16_unit48(act_grp[t], static_cast<unsigned>(p.slot_xyz) * (2 * kPieceBytes), static_cast<unsigned>(ln) * 16u,
                              make_uint4(cv(a[0], a[1]), cv(a[2], a[3]), cv(b[0], b[1]), cv(b[2], b[3])));
         }
       }
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       if constexpr (SAVE != 0) {
         constexpr int t = decltype(t_c)::value;
         const u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
-        store16_uniform_at(act_grp[t], static_cast<unsigned>(slot) * (2 * kPieceBytes), pipe.lane16,
+        store16_unit48(act_grp[t], static_cast<unsigned>(slot) * (2 * kPieceBytes), pipe.lane16,
                            make_uint4(to_e4m3(a[0], a[1]), to_e4m3(a[2], a[3]), to_e4m3(b[0], b[1]), to_e4m3(b[2], b[3])));
       }
     };
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
               const unsigned w0 = to_e4m3(a[0], a[1]), w1 = to_e4m3(a[2], a[3]);
               const auto s0 = __builtin_amdgcn_permlane32_swap(w0, w0, false, false);   // [1]: lanes < 32 receive lane + 32's word
               const auto s1 = __builtin_amdgcn_permlane32_swap(w1, w1, false, false);
-              store16_uniform_at(act_grp[t], static_cast<unsigned>(p.slot_dir) * (2 * kPieceBytes), static_cast<unsigned>(ln) * 16u, make_uint4(w0, w1, s0[1], s1[1]));
+              store16_unit48(act_grp[t], static_cast<unsigned>(p.slot_dir) * (2 * kPieceBytes), static_cast<unsigned>(ln) * 16u, make_uint4(w0, w1, s0[1], s1[1]));
             }
             __builtin_amdgcn_sched_barrier(0);
           });

@@ -120,7 +120,9 @@ bool g48_range_guard_complete(const dn_mlp_desc& d);
 // consecutive groups form one 32-point record T = G / 2 - the unit of the weight-gradient kernel's K = 64 contraction.
 // Saved unit (1 KiB = 64 lanes x 16 bytes) of group G, slot s: lane (g = lane / 16, j = lane % 16) holds, for point j of the
 // group, the 8 + 8 bytes of B pieces 2s and 2s + 1 of the saved vector (byte b: piece 2s + b / 8, element b % 8 - feature
-// g48_hidden_col(piece, g, element) of a hidden vector, slot g48_pe_col of an encoding panel).  Address of a unit:
+// g48_hidden_col(piece, g, element) of a hidden vector, slot g48_pe_col of an encoding panel) - at row g * 16 + (j ^ 8 (g & 1)) of
+// the unit, not at its own lane's: the odd lane groups are stored with their two 8-point halves exchanged, which puts the
+// weight-gradient kernel's paired reads on different LDS banks (mlp_device.h store16_unit48).  Address of a unit:
 //   buffer + ((T * units_per_group + s) * 2 + (G & 1)) * 1 KiB
 // so that, seen from the weight-gradient kernel, a record is a run of 2 * units_per_group 1-KiB units and the two groups'
 // units of one slot sit side by side.  Buffers are sized for whole workgroup tiles (384 points = 12 records).

@@ -655,8 +655,11 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
   // the slot's two pieces; a 32-feature fragment of parity par takes rows g = 2 par + fs, a 16-lane group reads 8 of them (128
   // contiguous bytes, every LDS bank once): lane li supplies the 8-byte chunk (row li >> 1, half li & 1) and receives byte
   // column li.  Parity 1 sits 512 bytes further on; the record's second group one unit (PS) further on.
-  const int lane_off = S::S8 ? ((fs * 16 + (li >> 1)) * 16) + (li & 1) * 8
+  // The odd lane groups' rows are stored swizzled (point j at row j ^ 8: mlp_device.h store16_unit48): this lane's fs = 1 reads start
+  // 128 bytes in and step back, so the two 16-lane groups a 32-lane LDS cycle serves touch different halves of the 64 banks.
+  const int lane_off = S::S8 ? ((fs * 16 + (li >> 1)) * 16) + (li & 1) * 8 + fs * 128
                              : ((li & 3) >> 1) * PS + ((fs * 32 + (li >> 2) + 8 * hh) * 16) + ((li & 3) & 1) * 8;
+  const int swz = 128 - 256 * fs;   // (8-bit kernel) byte step from a group's first eight points to its second eight
 
   // ---- staging: each 1 KiB piece is one LDS-DMA (opaque asm: the counted waits below are ours; hipcc would drain
   // with vmcnt(0) at every barrier).  This wave stages pieces wave, wave + 8, ... of every tile.
@@ -776,11 +779,13 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
     constexpr int kOnes = 0x38383838;   // 1.0 in e4m3, four times
     // this lane's 32 K slots of one operand = the 32 points of its record: four 8-point transposing reads, two in the unit of
     // the record's first 16-point group, two in the second group's (the next staged unit)
-    auto read32 = [](const char* unit_lane) {
+    auto read32 = [swz](const char* unit_lane) {
       i32x8 o;
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(unit_lane + (f >> 1) * kPieceBytes + (f & 1) * 128));
+        // (f & 1: the second eight points of the group - 128 bytes further on for an even lane group, 128 bytes BACK for an odd one,
+        // whose rows are stored swizzled: `swz` below)
+        const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(unit_lane + (f >> 1) * kPieceBytes + (f & 1) * swz));
         o[2 * f] = v[0]; o[2 * f + 1] = v[1];
       }
       return o;

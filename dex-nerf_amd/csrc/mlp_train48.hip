@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
     auto save_unit = [&](auto t_c, int slot, const BP8& lo, const BP8& hi) {
       constexpr int t = decltype(t_c)::value;
       const u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
-      store16_uniform_at(grad_grp[t], static_cast<unsigned>(slot) * (2 * kPieceBytes), pipe.lane16,
+      store16_unit48(grad_grp[t], static_cast<unsigned>(slot) * (2 * kPieceBytes), pipe.lane16,
                          make_uint4(to_e5m2(a[0], a[1]), to_e5m2(a[2], a[3]), to_e5m2(b[0], b[1]), to_e5m2(b[2], b[3])));
     };
 
@@ -343,7 +343,7 @@ __global__ void unpack48_kernel(const char* __restrict__ buf, int units_per_grou
     const int lane = static_cast<int>((idx / 16) % 64);
     const int u = static_cast<int>((idx / 1024) % n_units);
     const long long G = idx / (1024LL * n_units);
-    const int g = lane >> 4, j = lane & 15;
+    const int g = lane >> 4, j = (lane & 15) ^ ((g & 1) << 3);   // (rows of the odd lane groups are swizzled: store16_unit48)
     const long long pt = G * 16 + j;
     if (pt >= n_points) continue;
     int col;

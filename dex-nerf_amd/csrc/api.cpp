@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "dn_common.h"
+#include "dn_rng.h"
 
 namespace dn {
 
@@ -135,29 +136,33 @@ extern "C" int dn_render_rays_train(const dn_mlp_desc* desc_coarse, const void* 
                                     const float* noise_c, const float* u, const float* noise_f, float* rgb_c,
                                     float* depth_c, float* acc_c, float* rgb_f, float* depth_f, float* acc_f, float* dex_f,
                                     void* workspace, void* act_c, void* masks_c, void* act_f, void* masks_f,
-                                    dn_stream_t stream) {
+                                    const uint32_t* rng_state, int perturb, dn_stream_t stream) {
   if (n_rays == 0) return 0;
   DN_REQUIRE(desc_coarse && packed_coarse && rays && workspace && act_c && masks_c && n_rays >= 0, "dn_render_rays_train: bad arguments");
   DN_REQUIRE(num_fine == 0 || (desc_fine && packed_fine && act_f && masks_f), "dn_render_rays_train: fine pass requested without a fine net / its buffers");
   DN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "dn_render_rays_train: workspace must be 256-byte aligned");
   Workspace w = carve(workspace, n_rays, num_coarse, num_fine, true);
   int rc;
-  if ((rc = dn_coarse_depths(rays, ray_stride, n_rays, num_coarse, lindisp, t_rand, w.z_c, stream))) return rc;
+  // a NULL draw with an RNG state: drawn in the kernels (dn_rng.h) - jitter / resampling u only when `perturb`, density noise
+  // whenever noise_std > 0; explicit draws win (parity tests inject the reference's)
+  const uint32_t* rng_perturb = perturb ? rng_state : nullptr;
+  if ((rc = coarse_depths_rng(rays, ray_stride, n_rays, num_coarse, lindisp, t_rand, w.z_c, rng_perturb, stream))) return rc;
   if ((rc = dn_run_network_train(desc_coarse, precision, packed_coarse, nullptr, nullptr, rays, ray_stride, w.z_c, n_rays,
                                  num_coarse, w.rf_c, act_c, masks_c, stream)))
     return rc;
   const bool fine = num_fine > 0;
-  if ((rc = dn_volume_render(w.rf_c, w.z_c, rays + 3, ray_stride, noise_c, noise_std, white_background, h_m_thres,
-                             fine ? 0 : n_thres, n_rays, num_coarse, rgb_c, nullptr, acc_c, w.w_c, depth_c,
-                             fine ? nullptr : dex_f, stream)))
+  if ((rc = volume_render_counting(w.rf_c, w.z_c, rays + 3, ray_stride, noise_c, noise_std, white_background, h_m_thres,
+                                   fine ? 0 : n_thres, n_rays, num_coarse, rgb_c, nullptr, acc_c, w.w_c, depth_c,
+                                   fine ? nullptr : dex_f, nullptr, stream, rng_state, kRngStreamNoiseCoarse)))
     return rc;
   if (!fine) return 0;
-  if ((rc = dn_fine_depths(w.z_c, w.w_c, u, n_rays, num_coarse, num_fine, w.z_f, nullptr, stream))) return rc;
+  if ((rc = fine_depths_rng(w.z_c, w.w_c, u, n_rays, num_coarse, num_fine, w.z_f, nullptr, rng_perturb, stream))) return rc;
   if ((rc = dn_run_network_train(desc_fine, precision, packed_fine, nullptr, nullptr, rays, ray_stride, w.z_f, n_rays,
                                  num_coarse + num_fine, w.rf_f, act_f, masks_f, stream)))
     return rc;
-  return dn_volume_render(w.rf_f, w.z_f, rays + 3, ray_stride, noise_f, noise_std, white_background, h_m_thres, n_thres,
-                          n_rays, num_coarse + num_fine, rgb_f, nullptr, acc_f, nullptr, depth_f, dex_f, stream);
+  return volume_render_counting(w.rf_f, w.z_f, rays + 3, ray_stride, noise_f, noise_std, white_background, h_m_thres, n_thres,
+                                n_rays, num_coarse + num_fine, rgb_f, nullptr, acc_f, nullptr, depth_f, dex_f, nullptr, stream,
+                                rng_state, kRngStreamNoiseFine);
 }
 
 extern "C" int dn_render_rays_backward(const dn_mlp_desc* desc_coarse, const void* packed_bwd_coarse,
@@ -168,7 +173,8 @@ extern "C" int dn_render_rays_backward(const dn_mlp_desc* desc_coarse, const voi
                                        const float* g_rgb_f, const float* g_depth_f, const float* g_acc_f, void* workspace,
                                        const void* act_c, const void* masks_c, void* grads_c, const void* act_f,
                                        const void* masks_f, void* grads_f, float* const* h_dW_c, float* const* h_db_c,
-                                       float* const* h_dW_f, float* const* h_db_f, int nets, dn_stream_t stream) {
+                                       float* const* h_dW_f, float* const* h_db_f, int nets, const uint32_t* rng_state,
+                                       dn_stream_t stream) {
   if (n_rays == 0) return 0;
   DN_REQUIRE(rays && workspace && n_rays >= 0 && (nets & ~3) == 0, "dn_render_rays_backward: bad arguments");
   DN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "dn_render_rays_backward: workspace must be 256-byte aligned");
@@ -176,10 +182,10 @@ extern "C" int dn_render_rays_backward(const dn_mlp_desc* desc_coarse, const voi
   int rc;
   auto half = [&](const dn_mlp_desc* desc, const void* packed_bwd, const float* rf, const float* z, int samples,
                   const float* noise, const float* g_rgb, const float* g_depth, const float* g_acc, const void* act,
-                  const void* masks, void* grads, float* const* h_dW, float* const* h_db) -> int {
+                  const void* masks, void* grads, float* const* h_dW, float* const* h_db, uint32_t noise_stream) -> int {
     DN_REQUIRE(desc && packed_bwd && act && masks && grads && h_dW && h_db, "dn_render_rays_backward: a network's buffers are missing");
-    if ((rc = dn_volume_render_backward(rf, z, rays + 3, ray_stride, noise, noise_std, white_background, n_rays, samples,
-                                        g_rgb, g_depth, g_acc, nullptr, nullptr, w.g_rf, stream)))
+    if ((rc = volume_render_backward_rng(rf, z, rays + 3, ray_stride, noise, noise_std, white_background, n_rays, samples,
+                                         g_rgb, g_depth, g_acc, nullptr, nullptr, w.g_rf, rng_state, noise_stream, stream)))
       return rc;
     const int64_t n_points = n_rays * samples;
     if ((rc = dn_mlp_backward_data(desc, precision, packed_bwd, w.g_rf, masks, n_points, grads, stream))) return rc;
@@ -189,12 +195,12 @@ extern "C" int dn_render_rays_backward(const dn_mlp_desc* desc_coarse, const voi
   // wants finished first so that its all-reduce overlaps the coarse half
   if ((nets & 2) && num_fine > 0) {
     if ((rc = half(desc_fine, packed_bwd_fine, w.rf_f, w.z_f, num_coarse + num_fine, noise_f, g_rgb_f, g_depth_f, g_acc_f,
-                   act_f, masks_f, grads_f, h_dW_f, h_db_f)))
+                   act_f, masks_f, grads_f, h_dW_f, h_db_f, kRngStreamNoiseFine)))
       return rc;
   }
   if (nets & 1) {
     if ((rc = half(desc_coarse, packed_bwd_coarse, w.rf_c, w.z_c, num_coarse, noise_c, g_rgb_c, g_depth_c, g_acc_c, act_c,
-                   masks_c, grads_c, h_dW_c, h_db_c)))
+                   masks_c, grads_c, h_dW_c, h_db_c, kRngStreamNoiseCoarse)))
       return rc;
   }
   return 0;

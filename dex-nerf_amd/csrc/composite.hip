@@ -7,6 +7,7 @@
 // and rounds each prefix to fp32), the Dex readout is a ballot + first-set-bit per threshold.
 // HBM-bound: 20 B/sample in (rf float4 + z), (10+K)*4 B/ray out.
 #include "dn_common.h"
+#include "dn_rng.h"
 
 namespace dn {
 
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float4* __restrict__ rf, const float* __restrict__ z, const float* __restrict__ rd, int rd_stride,
     const float* __restrict__ noise, float noise_std, int white, ThresArgs th, int n_thres, int64_t n_rays, int S,
     float* __restrict__ rgb, float* __restrict__ disp, float* __restrict__ acc, float* __restrict__ weights,
-    float* __restrict__ depth, float* __restrict__ dex, unsigned* __restrict__ nonfinite) {
+    float* __restrict__ depth, float* __restrict__ dex, unsigned* __restrict__ nonfinite, RngRef rng) {
   const int lane = lane_id();
   const int64_t ray = static_cast<int64_t>(blockIdx.x) * kRaysPerBlock + (threadIdx.x >> 6);
   if (ray >= n_rays) return;  // wave-uniform exit; no block-level sync in this kernel
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     }
     const float z0 = zr[sc];
     const float z1 = (sc + 1 < S) ? zr[sc + 1] : z0;
-    const float nz = (noise != nullptr && noise_std > 0.0f) ? noise[ray * S + sc] : 0.0f;
+    const float nz = noise_std > 0.0f ? (noise != nullptr ? noise[ray * S + sc]
+                                                          : (rng.state != nullptr ? rng_normal(rng, static_cast<uint64_t>(ray) * S + sc) : 0.0f)) : 0.0f;
     const SampleTerms t = sample_terms(raw.w, nz, noise_std, z0, z1, sc == S - 1, rd_norm);
     const double f = valid ? static_cast<double>(t.one_m_alpha) : 1.0;
     const double incl = wave_scan_mul(f) * carry;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float4* __restrict__ rf, const float* __restrict__ z, const float* __restrict__ rd, int rd_stride,
     const float* __restrict__ noise, float noise_std, int white, int64_t n_rays, int S, const float* __restrict__ g_rgb,
     const float* __restrict__ g_depth, const float* __restrict__ g_acc, const float* __restrict__ g_disp,
-    const float* __restrict__ g_weights, float4* __restrict__ g_rf) {
+    const float* __restrict__ g_weights, float4* __restrict__ g_rf, RngRef rng) {
   const int lane = lane_id();
   const int64_t ray = static_cast<int64_t>(blockIdx.x) * kRaysPerBlock + (threadIdx.x >> 6);
   if (ray >= n_rays) return;
@@ -162,7 +164,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float4 raw = rfr[sc];
     const float z0 = zr[sc];
     const float z1 = (sc + 1 < S) ? zr[sc + 1] : z0;
-    const float nz = (noise != nullptr && noise_std > 0.0f) ? noise[ray * S + sc] : 0.0f;
+    // (the forward's noise again: the same pure function of (seed, iteration, stream, element) when it was drawn in the kernel)
+    const float nz = noise_std > 0.0f ? (noise != nullptr ? noise[ray * S + sc]
+                                                          : (rng.state != nullptr ? rng_normal(rng, static_cast<uint64_t>(ray) * S + sc) : 0.0f)) : 0.0f;
     const SampleTerms t = sample_terms(raw.w, nz, noise_std, z0, z1, sc == S - 1, rd_norm);
     const double f = valid ? static_cast<double>(t.one_m_alpha) : 1.0;
     const double incl = wave_scan_mul(f) * carry;
@@ -236,7 +240,8 @@ extern "C" int dn_volume_render(const float* rf, const float* z, const float* rd
 int dn::volume_render_counting(const float* rf, const float* z, const float* rd, int rd_stride, const float* noise,
                                float noise_std, int white_background, const float* h_m_thres, int n_thres,
                                int64_t n_rays, int n_samples, float* rgb, float* disp, float* acc, float* weights,
-                               float* depth, float* dex, unsigned* nonfinite, dn_stream_t stream) {
+                               float* depth, float* dex, unsigned* nonfinite, dn_stream_t stream, const uint32_t* rng_state,
+                               uint32_t rng_stream) {
   if (n_rays == 0) return 0;
   DN_REQUIRE(rf && z && rd && n_rays >= 0 && n_samples >= 1 && rd_stride >= 3, "dn_volume_render: bad arguments");
   DN_REQUIRE(n_thres >= 0 && n_thres <= kMaxThres, "dn_volume_render: at most %d Dex thresholds", kMaxThres);
@@ -248,7 +253,7 @@ int dn::volume_render_counting(const float* rf, const float* z, const float* rd,
   const unsigned grid = static_cast<unsigned>((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
   hipLaunchKernelGGL(composite_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float4*>(rf), z, rd, rd_stride, noise, noise_std, white_background, th,
-                     n_thres, n_rays, n_samples, rgb, disp, acc, weights, depth, dex, nonfinite);
+                     n_thres, n_rays, n_samples, rgb, disp, acc, weights, depth, dex, nonfinite, RngRef{rng_state, rng_stream});
   return check_launch("dn_volume_render");
 }
 
@@ -257,6 +262,14 @@ extern "C" int dn_volume_render_backward(const float* rf, const float* z, const 
                                          int n_samples, const float* g_rgb, const float* g_depth, const float* g_acc,
                                          const float* g_disp, const float* g_weights, float* g_rf,
                                          dn_stream_t stream) {
+  return dn::volume_render_backward_rng(rf, z, rd, rd_stride, noise, noise_std, white_background, n_rays, n_samples, g_rgb, g_depth, g_acc,
+                                        g_disp, g_weights, g_rf, nullptr, 0u, stream);
+}
+
+int dn::volume_render_backward_rng(const float* rf, const float* z, const float* rd, int rd_stride, const float* noise, float noise_std,
+                                   int white_background, int64_t n_rays, int n_samples, const float* g_rgb, const float* g_depth,
+                                   const float* g_acc, const float* g_disp, const float* g_weights, float* g_rf,
+                                   const uint32_t* rng_state, uint32_t rng_stream, dn_stream_t stream) {
   if (n_rays == 0) return 0;
   DN_REQUIRE(rf && z && rd && g_rf && n_rays >= 0 && n_samples >= 1 && rd_stride >= 3,
              "dn_volume_render_backward: bad arguments");
@@ -269,7 +282,7 @@ extern "C" int dn_volume_render_backward(const float* rf, const float* z, const 
 #define DN_LAUNCH_BWD(MC)                                                                                          \
   hipLaunchKernelGGL(composite_bwd_kernel<MC>, dim3(grid), dim3(256), 0, as_stream(stream),                        \
                      reinterpret_cast<const float4*>(rf), z, rd, rd_stride, noise, noise_std, white_background,    \
-                     n_rays, n_samples, g_rgb, g_depth, g_acc, g_disp, g_weights, reinterpret_cast<float4*>(g_rf))
+                     n_rays, n_samples, g_rgb, g_depth, g_acc, g_disp, g_weights, reinterpret_cast<float4*>(g_rf), RngRef{rng_state, rng_stream})
   if (chunks <= 1) DN_LAUNCH_BWD(1);
   else if (chunks <= 2) DN_LAUNCH_BWD(2);
   else if (chunks <= 4) DN_LAUNCH_BWD(4);

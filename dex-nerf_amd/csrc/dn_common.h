@@ -37,13 +37,24 @@ int device_cus();
 int volume_render_counting(const float* rf, const float* z, const float* rd, int rd_stride, const float* noise, float noise_std,
                            int white_background, const float* h_m_thres, int n_thres, int64_t n_rays, int n_samples, float* rgb,
                            float* disp, float* acc, float* weights, float* depth, float* dex, unsigned* nonfinite,
-                           dn_stream_t stream);
+                           dn_stream_t stream, const uint32_t* rng_state = nullptr, uint32_t rng_stream = 0);
 
 // mlp_fused.hip: dn_run_network with the fp16 range flag (a device word the 48-point fp16 kernel bumps when a hidden activation
 // left fp16's range; NULL = not wanted)
 int run_network_flagged(const dn_mlp_desc* desc, int precision, const void* packed, const float* pts, const float* viewdirs,
                         const float* rays, int ray_stride, const float* z_vals, int64_t n_rays, int samples_per_ray, float* out,
                         unsigned* range_flag, dn_stream_t stream);
+
+// rays_sampling.hip / composite.hip: the stage entry points with an RNG state (dn_rng.h) - a NULL draw pointer together with a
+// state means "draw it in the kernel"
+int coarse_depths_rng(const float* rays, int ray_stride, int64_t n_rays, int num_coarse, int lindisp, const float* t_rand,
+                      float* z_vals, const uint32_t* rng_state, dn_stream_t stream);
+int fine_depths_rng(const float* z_coarse, const float* weights, const float* u, int64_t n_rays, int num_coarse, int num_fine,
+                    float* z_fine, float* z_samples, const uint32_t* rng_state, dn_stream_t stream);
+int volume_render_backward_rng(const float* rf, const float* z, const float* rd, int rd_stride, const float* noise, float noise_std,
+                               int white_background, int64_t n_rays, int n_samples, const float* g_rgb, const float* g_depth,
+                               const float* g_acc, const float* g_disp, const float* g_weights, float* g_rf,
+                               const uint32_t* rng_state, uint32_t rng_stream, dn_stream_t stream);
 
 #define DN_REQUIRE(cond, ...)     \
   do {                            \

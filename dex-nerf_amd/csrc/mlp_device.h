@@ -698,8 +698,10 @@ __device__ __forceinline__ void store16_unit48(const char* base, unsigned byte_o
   const unsigned voff = lane16;
   const f32x4 data = __builtin_bit_cast(f32x4, val);
   unsigned tmp;
+  // (wait states between a VALU write of the base SGPRs - an SGPR-spill restore by v_readlane_b32 can sit right in front of this
+  // statement - and the store: the four address instructions + s_nop 0 = 5)
   asm volatile("v_and_b32 %[tmp], 0x100, %[voff]\n\tv_lshrrev_b32 %[tmp], 1, %[tmp]\n\tv_xor_b32 %[tmp], %[tmp], %[voff]\n\tv_add_u32 %[tmp], %[off], %[tmp]\n\t"
-               "s_nop 4\n\tglobal_store_dwordx4 %[tmp], %[data], %[sbase]" DN_STORE_POLICY "\n\ts_nop 1"
+               "s_nop 0\n\tglobal_store_dwordx4 %[tmp], %[data], %[sbase]" DN_STORE_POLICY "\n\ts_nop 1"
                : [tmp] "=&v"(tmp) : [voff] "v"(voff), [off] "s"(off), [data] "v"(data), [sbase] "s"(b) : "memory");
 }
 

@@ -2,6 +2,7 @@
 // coarse+fine depth merge.  HBM-bound elementwise / wave-scan kernels (one wave64 per ray for the
 // sampler); compiled with -ffp-contract=off so plain mul/add sequences round like ATen's.
 #include "dn_common.h"
+#include "dn_rng.h"
 
 namespace dn {
 
@@ -88,16 +89,29 @@ __global__ void select_rays_kernel(RayBundleArgs a, float near, float far, const
 // The same with the camera chosen on the device: `cams` holds one 16-float record per training view
 // [rinv9, origin3, fx, cx, cy, -] and `view` is a device scalar, so a captured HIP graph of the whole training
 // iteration can be replayed for any view (host-side camera constants would be frozen into the graph).
+// pix == NULL: the pixels are DRAWN here - element i of this iteration's draw without replacement, a keyed permutation of the
+// H W pixels (dn_rng.h feistel_permute; reference train_dexnerf_rgb.py:229-236: np.random.choice(H W, n, replace=False)) - from
+// the RNG state's NEXT iteration counter, which thread 0 then publishes as the CURRENT one for the rest of the iteration.
 __global__ void select_rays_indirect_kernel(const float* __restrict__ cams, const int* __restrict__ view, int height, int width,
                                             float near, float far, const int64_t* __restrict__ pix, int64_t n,
                                             const float* __restrict__ images, int channels, float* __restrict__ rays,
-                                            float* __restrict__ target) {
+                                            float* __restrict__ target, uint32_t* __restrict__ rng_state, int64_t* __restrict__ pix_out) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  uint32_t iteration = 0;
+  if (pix == nullptr) {
+    iteration = rng_state[3];
+    if (i == 0) rng_state[2] = iteration;   // (nobody in this launch reads word 2)
+  }
   if (i >= n) return;
   const int v = *view;
   const float* cam = cams + static_cast<int64_t>(v) * 16;
   const float fx = cam[12], cx = cam[13], cy = cam[14];
-  const int64_t px = pix[i];
+  int64_t px;
+  if (pix != nullptr) px = pix[i];
+  else {
+    px = feistel_permute(static_cast<uint32_t>(i), static_cast<uint32_t>(height) * static_cast<uint32_t>(width), rng_state[0], rng_state[1], iteration);
+    if (pix_out != nullptr) pix_out[i] = px;
+  }
   const int row = static_cast<int>(px / width);
   const int col = static_cast<int>(px - static_cast<int64_t>(row) * width);
   const float d0 = (static_cast<float>(col) - cx) / fx;
@@ -160,7 +174,7 @@ __device__ __forceinline__ float coarse_z_at(float near, float far, int nc, int 
 }
 
 __global__ void coarse_depths_kernel(const float* __restrict__ rays, int ray_stride, int64_t n_rays, int nc,
-                                     int lindisp, const float* __restrict__ t_rand, float* __restrict__ z) {
+                                     int lindisp, const float* __restrict__ t_rand, float* __restrict__ z, RngRef rng) {
   const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (idx >= n_rays * nc) return;
   const int64_t r = idx / nc;
@@ -168,7 +182,7 @@ __global__ void coarse_depths_kernel(const float* __restrict__ rays, int ray_str
   const float near = rays[r * ray_stride + 6];
   const float far = rays[r * ray_stride + 7];
   const float zi = coarse_z_at(near, far, nc, i, lindisp);
-  if (t_rand == nullptr) {
+  if (t_rand == nullptr && rng.state == nullptr) {
     z[idx] = zi;
     return;
   }
@@ -176,7 +190,8 @@ __global__ void coarse_depths_kernel(const float* __restrict__ rays, int ray_str
   const float z_first = coarse_z_at(near, far, nc, 0, lindisp);
   const float upper = (i < nc - 1) ? 0.5f * (coarse_z_at(near, far, nc, i + 1, lindisp) + zi) : z_last;
   const float lower = (i > 0) ? 0.5f * (zi + coarse_z_at(near, far, nc, i - 1, lindisp)) : z_first;
-  z[idx] = lower + (upper - lower) * t_rand[idx];
+  const float t = (t_rand != nullptr) ? t_rand[idx] : rng_uniform(rng, static_cast<uint64_t>(idx));   // (drawn here: dn_rng.h)
+  z[idx] = lower + (upper - lower) * t;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -309,7 +324,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void sampler_kernel(const float* __restrict__ bins_or_z, const float* __restrict__ weights,
                                                       const float* __restrict__ u, int64_t n_rays, int B, int nf,
                                                       float* __restrict__ samples, int64_t* __restrict__ inds,
-                                                      float* __restrict__ z_fine, int sort_len) {
+                                                      float* __restrict__ z_fine, int sort_len, RngRef rng) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
@@ -336,7 +351,8 @@ __global__ __launch_bounds__(256) void sampler_kernel(const float* __restrict__ 
   build_cdf(w, cdf, B);
   wave_lds_sync();
   for (int q = lane; q < nf; q += 64) {
-    const float uq = (u != nullptr) ? u[ray * nf + q] : linspace_elem(0.0f, 1.0f, nf, q);
+    const float uq = (u != nullptr) ? u[ray * nf + q]
+                     : (rng.state != nullptr ? rng_uniform(rng, static_cast<uint64_t>(ray) * nf + q) : linspace_elem(0.0f, 1.0f, nf, q));
     int ind;
     const float s = invert_cdf(cdf, bins, B, uq, &ind);
     if (live) {
@@ -469,8 +485,99 @@ extern "C" int dn_select_rays_indirect(int height, int width, const float* cams,
   const int block = 256;
   const unsigned grid = static_cast<unsigned>((n_rays + block - 1) / block);
   hipLaunchKernelGGL(select_rays_indirect_kernel, dim3(grid), dim3(block), 0, as_stream(stream), cams, view, height, width, near,
-                     far, pixel_index, n_rays, images, channels, rays, target);
+                     far, pixel_index, n_rays, images, channels, rays, target, static_cast<uint32_t*>(nullptr), static_cast<int64_t*>(nullptr));
   return check_launch("dn_select_rays_indirect");
+}
+
+extern "C" int dn_select_rays_draw(int height, int width, const float* cams, const int32_t* view, float near, float far,
+                                   uint32_t* rng_state, int64_t n_rays, const float* images, int channels, float* rays, float* target,
+                                   int64_t* pixel_index_out, dn_stream_t stream) {
+  DN_REQUIRE(height > 0 && width > 0 && cams && view && rng_state && rays && n_rays >= 1, "dn_select_rays_draw: bad arguments");
+  DN_REQUIRE(n_rays <= static_cast<int64_t>(height) * width, "dn_select_rays_draw: more rays than pixels (the draw is without replacement)");
+  DN_REQUIRE(static_cast<int64_t>(height) * width < (1LL << 31), "dn_select_rays_draw: image too large");
+  DN_REQUIRE(target == nullptr || (images != nullptr && channels >= 3), "dn_select_rays_draw: target requested without images of >= 3 channels");
+  const int block = 256;
+  const unsigned grid = static_cast<unsigned>((n_rays + block - 1) / block);
+  hipLaunchKernelGGL(select_rays_indirect_kernel, dim3(grid), dim3(block), 0, as_stream(stream), cams, view, height, width, near,
+                     far, static_cast<const int64_t*>(nullptr), n_rays, images, channels, rays, target, rng_state, pixel_index_out);
+  return check_launch("dn_select_rays_draw");
+}
+
+// ---- S9 loss head on the device: mse(rgb_coarse, target) + mse(rgb_fine, target) (train_dexnerf_rgb.py:264-277; with
+// `luminance` the IR head of train_nerf_ir.py:260-263: both sides through 0.299 r + 0.587 g + 0.114 b first), the upstream
+// gradients of the two rgb maps written where dn_render_rays_backward reads them, and the RNG state's iteration counter advanced.
+// One workgroup: the sums are formed in a fixed order (deterministic); n is a training batch (<= a few thousand rays).
+namespace dn {
+__global__ __launch_bounds__(1024) void mse2_loss_kernel(const float* __restrict__ rgb_c, const float* __restrict__ rgb_f,
+                                                         const float* __restrict__ target, int64_t n, int luminance,
+                                                         float* __restrict__ out3, float* __restrict__ g_c, float* __restrict__ g_f,
+                                                         uint32_t* __restrict__ rng_state) {
+  __shared__ float part[2][16];
+  float sc = 0.0f, sf = 0.0f;
+  if (luminance) {
+    const float inv = 2.0f / static_cast<float>(n);
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+      const float lt = (0.299f * target[i * 3] + 0.587f * target[i * 3 + 1]) + 0.114f * target[i * 3 + 2];
+      const float* src[2] = {rgb_c, rgb_f};
+      float* dst[2] = {g_c, g_f};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (src[k] == nullptr) continue;
+        const float d = ((0.299f * src[k][i * 3] + 0.587f * src[k][i * 3 + 1]) + 0.114f * src[k][i * 3 + 2]) - lt;
+        (k ? sf : sc) += d * d;
+        if (dst[k] != nullptr) { dst[k][i * 3] = inv * d * 0.299f; dst[k][i * 3 + 1] = inv * d * 0.587f; dst[k][i * 3 + 2] = inv * d * 0.114f; }
+      }
+    }
+  } else {
+    const float inv = 2.0f / static_cast<float>(3 * n);
+    for (int64_t e = threadIdx.x; e < 3 * n; e += blockDim.x) {
+      const float t = target[e];
+      const float dc = rgb_c[e] - t;
+      sc += dc * dc;
+      if (g_c != nullptr) g_c[e] = inv * dc;
+      if (rgb_f != nullptr) {
+        const float df = rgb_f[e] - t;
+        sf += df * df;
+        if (g_f != nullptr) g_f[e] = inv * df;
+      }
+    }
+  }
+  sc = wave_sum(sc); sf = wave_sum(sf);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { part[0][wave] = sc; part[1][wave] = sf; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f, b = 0.0f;
+    for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) { a += part[0][w]; b += part[1][w]; }
+    const float denom = static_cast<float>(luminance ? n : 3 * n);
+    out3[1] = a / denom; out3[2] = b / denom; out3[0] = a / denom + b / denom;
+    if (rng_state != nullptr) rng_state[3] = rng_state[2] + 1u;   // the next iteration's counter (dn_rng.h)
+  }
+}
+}  // namespace dn
+
+namespace dn {
+__global__ void rng_fill_kernel(const uint32_t* __restrict__ state, uint32_t stream, int64_t n, int normal, float* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const RngRef r{state, stream};
+  out[i] = normal ? rng_normal(r, static_cast<uint64_t>(i)) : rng_uniform(r, static_cast<uint64_t>(i));
+}
+}  // namespace dn
+
+extern "C" int dn_rng_fill(const uint32_t* rng_state, uint32_t stream_id, int64_t n, int normal, float* out, dn_stream_t stream) {
+  if (n == 0) return 0;
+  DN_REQUIRE(rng_state && out && n >= 0, "dn_rng_fill: bad arguments");
+  hipLaunchKernelGGL(rng_fill_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, as_stream(stream), rng_state, stream_id, n, normal, out);
+  return check_launch("dn_rng_fill");
+}
+
+extern "C" int dn_mse2_loss(const float* rgb_coarse, const float* rgb_fine, const float* target, int64_t n_rays, int luminance,
+                            float* loss3, float* g_rgb_coarse, float* g_rgb_fine, uint32_t* rng_state, dn_stream_t stream) {
+  DN_REQUIRE(rgb_coarse && target && loss3 && n_rays >= 1, "dn_mse2_loss: bad arguments");
+  hipLaunchKernelGGL(mse2_loss_kernel, dim3(1), dim3(1024), 0, as_stream(stream), rgb_coarse, rgb_fine, target, n_rays, luminance, loss3,
+                     g_rgb_coarse, g_rgb_fine, rng_state);
+  return check_launch("dn_mse2_loss");
 }
 
 extern "C" int dn_ndc_rays(int height, int width, double focal, double near, const float* rays_o, const float* rays_d,
@@ -486,13 +593,19 @@ extern "C" int dn_ndc_rays(int height, int width, double focal, double near, con
 
 extern "C" int dn_coarse_depths(const float* rays, int ray_stride, int64_t n_rays, int num_coarse, int lindisp,
                                 const float* t_rand, float* z_vals, dn_stream_t stream) {
+  return dn::coarse_depths_rng(rays, ray_stride, n_rays, num_coarse, lindisp, t_rand, z_vals, nullptr, stream);
+}
+
+// dn_coarse_depths; t_rand == NULL with an RNG state: the stratified jitter is drawn in the kernel (dn_rng.h)
+int dn::coarse_depths_rng(const float* rays, int ray_stride, int64_t n_rays, int num_coarse, int lindisp,
+                                const float* t_rand, float* z_vals, const uint32_t* rng_state, dn_stream_t stream) {
   if (n_rays == 0) return 0;  // empty tensors carry NULL data pointers
   DN_REQUIRE(rays && z_vals && n_rays >= 0 && num_coarse >= 1 && ray_stride >= 8, "dn_coarse_depths: bad arguments");
   const int64_t total = n_rays * num_coarse;
   const int block = 256;
   const unsigned grid = static_cast<unsigned>((total + block - 1) / block);
   hipLaunchKernelGGL(coarse_depths_kernel, dim3(grid), dim3(block), 0, as_stream(stream), rays, ray_stride, n_rays,
-                     num_coarse, lindisp, t_rand, z_vals);
+                     num_coarse, lindisp, t_rand, z_vals, RngRef{rng_state, kRngStreamJitter});
   return check_launch("dn_coarse_depths");
 }
 
@@ -536,12 +649,18 @@ extern "C" int dn_sample_pdf(const float* bins, const float* weights, const floa
   const size_t lds = static_cast<size_t>(kSamplerWaves) * 3 * (n_bins + 1) * sizeof(float);
   const unsigned grid = static_cast<unsigned>((n_rays + kSamplerWaves - 1) / kSamplerWaves);
   hipLaunchKernelGGL(sampler_kernel<0>, dim3(grid), dim3(256), lds, as_stream(stream), bins, weights, u, n_rays,
-                     n_bins, n_samples, samples, inds, static_cast<float*>(nullptr), 0);
+                     n_bins, n_samples, samples, inds, static_cast<float*>(nullptr), 0, RngRef{nullptr, 0u});
   return check_launch("dn_sample_pdf");
 }
 
 extern "C" int dn_fine_depths(const float* z_coarse, const float* weights, const float* u, int64_t n_rays,
                               int num_coarse, int num_fine, float* z_fine, float* z_samples, dn_stream_t stream) {
+  return dn::fine_depths_rng(z_coarse, weights, u, n_rays, num_coarse, num_fine, z_fine, z_samples, nullptr, stream);
+}
+
+// dn_fine_depths; u == NULL with an RNG state: the resampling draws are made in the kernel (dn_rng.h), NULL without: deterministic
+int dn::fine_depths_rng(const float* z_coarse, const float* weights, const float* u, int64_t n_rays,
+                              int num_coarse, int num_fine, float* z_fine, float* z_samples, const uint32_t* rng_state, dn_stream_t stream) {
   if (n_rays == 0) return 0;
   DN_REQUIRE(z_coarse && weights && z_fine && n_rays >= 0 && num_fine >= 1, "dn_fine_depths: bad arguments");
   DN_REQUIRE(num_coarse >= 10 && num_coarse <= 512 && num_coarse + num_fine <= 2048,
@@ -552,6 +671,6 @@ extern "C" int dn_fine_depths(const float* z_coarse, const float* weights, const
   const size_t lds = static_cast<size_t>(kSamplerWaves) * (3 * (B + 1) + sort_len) * sizeof(float);
   const unsigned grid = static_cast<unsigned>((n_rays + kSamplerWaves - 1) / kSamplerWaves);
   hipLaunchKernelGGL(sampler_kernel<1>, dim3(grid), dim3(256), lds, as_stream(stream), z_coarse, weights, u, n_rays, B,
-                     num_fine, z_samples, static_cast<int64_t*>(nullptr), z_fine, sort_len);
+                     num_fine, z_samples, static_cast<int64_t*>(nullptr), z_fine, sort_len, RngRef{rng_state, kRngStreamU});
   return check_launch("dn_fine_depths");
 }

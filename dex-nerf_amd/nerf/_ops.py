@@ -134,6 +134,52 @@ def select_rays_indirect(height, width, cams, view, near, far, pixel_index, imag
     return rays, target
 
 
+def new_rng_state(seed, device, first_iteration=0):
+    """Device record {seed_lo, seed_hi, cur, nxt} for the in-kernel draws of a training loop (csrc/dn_rng.h)."""
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    words = [seed & 0xFFFFFFFF, seed >> 32, int(first_iteration) & 0xFFFFFFFF, int(first_iteration) & 0xFFFFFFFF]
+    return torch.tensor([w - (1 << 32) if w >= (1 << 31) else w for w in words], dtype=torch.int32, device=device)
+
+
+def rng_fill(rng_state, stream_id, shape, normal=False):
+    """The numbers the kernels draw for the current iteration from `rng_state`, stream `stream_id` (dn_rng_fill)."""
+    out = torch.empty(shape, dtype=torch.float32, device=rng_state.device)
+    check(lib().dn_rng_fill(ptr(rng_state), int(stream_id), out.numel(), int(bool(normal)), ptr(out), stream()), "dn_rng_fill")
+    return out
+
+
+def select_rays_draw(height, width, cams, view, near, far, rng_state, n_rays, images=None, want_pixels=False):
+    """select_rays_indirect with the pixels drawn on the device, without replacement, from `rng_state`'s next iteration."""
+    assert view.dtype == torch.int32 and cams.dtype == torch.float32 and cams.is_contiguous() and rng_state.dtype == torch.int32
+    dev = cams.device
+    rays = torch.empty((n_rays, 11), dtype=torch.float32, device=dev)
+    target, img, channels = None, None, 0
+    if images is not None:
+        img = f32c(images)
+        channels = img.shape[-1]
+        target = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
+    pix = torch.empty((n_rays,), dtype=torch.int64, device=dev) if want_pixels else None
+    check(lib().dn_select_rays_draw(height, width, ptr(cams), ptr(view), float(near), float(far), ptr(rng_state), n_rays, ptr(img), channels,
+                                    ptr(rays), ptr(target), ptr(pix), stream()), "dn_select_rays_draw")
+    return (rays, target, pix) if want_pixels else (rays, target)
+
+
+def mse2_loss(rgb_c, rgb_f, target, luminance=False, rng_state=None):
+    """(loss3 = [loss, mse_coarse, mse_fine] on the device, g_rgb_coarse, g_rgb_fine): the loss head + its upstream gradients in
+    one launch (dn_mse2_loss); advances `rng_state`'s iteration counter."""
+    rgb_c, target = f32c(rgb_c), f32c(target)
+    n = rgb_c.shape[0]
+    loss3 = torch.empty(3, dtype=torch.float32, device=rgb_c.device)
+    g_c = torch.empty_like(rgb_c)
+    g_f = None
+    if rgb_f is not None:
+        rgb_f = f32c(rgb_f)
+        g_f = torch.empty_like(rgb_f)
+    check(lib().dn_mse2_loss(ptr(rgb_c), ptr(rgb_f), ptr(target), n, int(bool(luminance)), ptr(loss3), ptr(g_c), ptr(g_f), ptr(rng_state),
+                             stream()), "dn_mse2_loss")
+    return loss3, g_c, g_f
+
+
 def ndc_rays(height, width, focal, near, rays_o, rays_d):
     ro, rd = f32c(rays_o), f32c(rays_d)
     n = ro.numel() // 3
@@ -512,7 +558,8 @@ def render_nonfinite_count(ws=None):
 
 
 # ---- predict_and_render_radiance under autograd: one C call forward, one (or two halves) backward ----------------------
-def render_rays_train(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, noise_std, white, m_thres, draws=None, prec=None):
+def render_rays_train(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, noise_std, white, m_thres, draws=None, prec=None,
+                      rng_state=None, perturb=False):
     """dn_render_rays_train: the training forward of a whole ray chunk.  Returns (maps, saved): maps = (rgb_c, depth_c, acc_c,
     rgb_f, depth_f, acc_f, dex), saved = what dn_render_rays_backward needs (workspace, per-network act / masks, the draws)."""
     rays = f32c(rays)
@@ -544,9 +591,10 @@ def render_rays_train(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, n
         ptr(rays), rays.shape[1], n, num_coarse, nf, int(bool(lindisp)), float(noise_std), int(bool(white)),
         host_floats(m_thres), k, ptr(t["t_rand"]), ptr(t["noise_c"]), ptr(t["u"]), ptr(t["noise_f"]),
         ptr(rgb_c), ptr(depth_c), ptr(acc_c), ptr(rgb_f), ptr(depth_f), ptr(acc_f), ptr(dex), ptr(ws),
-        ptr(act_c), ptr(masks_c), ptr(act_f), ptr(masks_f), stream()), "dn_render_rays_train")
+        ptr(act_c), ptr(masks_c), ptr(act_f), ptr(masks_f), ptr(rng_state), int(bool(perturb)), stream()), "dn_render_rays_train")
     saved = dict(rays=rays, ws=ws, act_c=act_c, masks_c=masks_c, act_f=act_f, masks_f=masks_f, noise_c=t["noise_c"],
-                 noise_f=t["noise_f"], n=n, nc=num_coarse, nf=nf, noise_std=float(noise_std), white=bool(white), prec=prec)
+                 noise_f=t["noise_f"], n=n, nc=num_coarse, nf=nf, noise_std=float(noise_std), white=bool(white), prec=prec,
+                 rng_state=rng_state)
     return (rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f, dex), saved
 
 
@@ -578,5 +626,5 @@ def render_rays_backward(packed_c, packed_f, saved, g_c, g_f, views_c, views_f, 
         ptr(saved["rays"]), saved["rays"].shape[1], n, nc, nf, saved["noise_std"], int(saved["white"]),
         ptr(saved["noise_c"]), ptr(saved["noise_f"]), ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]), ptr(gs[5]),
         ptr(saved["ws"]), ptr(saved["act_c"]), ptr(saved["masks_c"]), ptr(grads_c), ptr(saved["act_f"]), ptr(saved["masks_f"]),
-        ptr(grads_f), wc, bc, wf, bf, int(nets), stream()), "dn_render_rays_backward")
+        ptr(grads_f), wc, bc, wf, bf, int(nets), ptr(saved.get("rng_state")), stream()), "dn_render_rays_backward")
     return grads_c, grads_f   # (kept alive by the caller until the stream has consumed them: PyTorch's caching allocator is stream-ordered)

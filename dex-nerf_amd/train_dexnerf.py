@@ -152,6 +152,9 @@ def main(argv=None):
     ap.add_argument("--near", type=float, default=None, help="default 2 (synthetic scene) / 0.3 (MessyTable)")
     ap.add_argument("--far", type=float, default=None, help="default 6 (synthetic scene) / 4 (MessyTable)")
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--autograd-step", action="store_true",
+                    help="run the iteration as torch ops + autograd over the fused kernels (torch.randperm / rand / randn draws, mse_loss, "
+                         "loss.backward()) instead of nerf.FusedTrainStep")
     ap.add_argument("--no-hip-graph", action="store_true",
                     help="launch every kernel of an iteration from Python instead of replaying one captured HIP graph "
                          "(single-GPU runs capture by default: the as-shipped 4x128 nets at 1024 rays are launch-bound)")
@@ -221,9 +224,22 @@ def main(argv=None):
                                          args.near, args.far,
                                          images=torch.stack([images[v].reshape(hw[0], hw[1], 3) for v in train_ids]), device=dev)
     loss_t = torch.zeros((), dtype=torch.float32, device=dev)
+    # The whole iteration on this library's kernels (nerf.FusedTrainStep: pixel draw, jitter, resampling and density noise drawn
+    # inside the kernels, loss head + upstream gradients in one launch, no autograd graph) wherever the fused training kernels
+    # cover the configuration; --autograd-step keeps the torch composition (torch.randperm / rand / randn, autograd).
+    fused = None
+    if not args.autograd_step and nerf.FusedTrainStep.applicable(student[0], student[1], cfg, ex, ed, args.num_random_rays) and not args.ndc:
+        fused = nerf.FusedTrainStep(student[0], student[1], selector, cfg, bucket, ex, ed, args.num_random_rays, seed=args.seed + 7919 * rank,
+                                    luminance=args.ir, first_iteration=start)
 
     def iteration():
         """select rays -> coarse + fine render -> loss -> backward -> (all-reduce) -> Adam; device-side state only."""
+        if fused is not None:
+            loss3 = fused.forward_backward()
+            bucket.all_reduce_mean()
+            opt.step()
+            loss_t.copy_(loss3[0])
+            return
         rays, target = selector.select(selector.random_pixels(args.num_random_rays))
         if args.ndc:
             # run_one_iter_of_nerf's NDC branch (reference train_utils.py:240-262) on the selected rows: origins / directions

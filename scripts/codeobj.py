@@ -135,7 +135,7 @@ def _wait_states(line):
 
 
 def sgpr_base_vmem_violations(ins, need=5):
-    """VALU writes an SGPR (v_readfirstlane_b32 / v_cmp* writing an SGPR pair) -> a VMEM instruction reads that SGPR as its
+    """VALU writes an SGPR (v_readfirstlane_b32, v_readlane_b32) -> a VMEM instruction reads that SGPR as its
     base: the gfx9 / CDNA hazard table asks for 5 wait states in between, and the hazard recognizer cannot see into the
     opaque asm statements that hold our SGPR-base global_store_dwordx4 / global_load_lds_dwordx4.  Returns
     [(writer index, writer, vmem index, vmem, wait states seen)]."""
@@ -150,7 +150,7 @@ def sgpr_base_vmem_violations(ins, need=5):
         states, j = 0, i - 1
         while j >= 0 and states < need:
             wop, wops = split_ins(ins[j])
-            if wop == "v_readfirstlane_b32" and regs_of(wops[0]) & sregs:
+            if wop in ("v_readfirstlane_b32", "v_readlane_b32") and regs_of(wops[0]) & sregs:   # (v_readlane: SGPR-spill restores)
                 bad.append((j, ins[j], i, line, states))
                 break
             if wop.startswith("s_cbranch") or wop == "s_barrier" or wop == "s_endpgm":

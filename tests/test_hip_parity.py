@@ -1531,6 +1531,140 @@ def test_bench_multi_gpu_leg_rehearsal_two_ranks_one_gpu(dev):
     assert dp["rays_per_s"] > 0 and dp["allreduce_ms"] > 0 and dp["roofline"]["bound"] == "hbm"
 
 
+# ---- the draws of a training iteration made on the device (csrc/dn_rng.h, nerf.FusedTrainStep) ---------------------------------
+def test_device_pixel_draw_is_a_permutation_with_uniform_marginals(dev):
+    """dn_select_rays_draw: the pixels of an iteration are a keyed permutation of the H W pixels, so ANY prefix is a draw without
+    replacement (reference: np.random.choice(H W, n, replace=False), train_dexnerf_rgb.py:229-236).  Checked: a full-length draw
+    hits every pixel exactly once (several image sizes, incl. non-powers of two); consecutive iterations give different draws, the
+    same (seed, iteration) the same one; over 4,000 iterations of 256-ray draws on a 37 x 29 image every pixel is chosen about
+    equally often (chi-square over the 1,073 pixels within 5 sigma of its mean) and no draw repeats a pixel; the ray rows and
+    targets equal dn_select_rays_indirect's on the drawn pixels."""
+    from nerf import _ops
+    cams = torch.zeros(2, 16, device=dev)
+    cams[:, 0] = cams[:, 4] = cams[:, 8] = 1.0
+    cams[:, 12], cams[:, 13], cams[:, 14] = 50.0, 3.0, 2.0
+    view = torch.zeros((), dtype=torch.int32, device=dev)
+    for (h, w) in ((4, 4), (37, 29), (64, 64), (100, 75)):
+        st = _ops.new_rng_state(11, dev)
+        _, _, pix = _ops.select_rays_draw(h, w, cams, view, 2.0, 6.0, st, h * w, want_pixels=True)
+        assert torch.equal(torch.sort(pix)[0], torch.arange(h * w, device=dev))
+        assert st.tolist()[2] == 0 and st.tolist()[3] == 0          # the draw publishes nxt as cur; only the loss kernel advances nxt
+        again = _ops.select_rays_draw(h, w, cams, view, 2.0, 6.0, _ops.new_rng_state(11, dev), h * w, want_pixels=True)[2]
+        assert torch.equal(pix, again)
+        other = _ops.select_rays_draw(h, w, cams, view, 2.0, 6.0, _ops.new_rng_state(11, dev, first_iteration=1), h * w, want_pixels=True)[2]
+        assert h * w < 32 or not torch.equal(pix, other)
+    h, w, n = 37, 29, 256
+    images = torch.rand(2, h, w, 3, device=dev)
+    counts = torch.zeros(h * w, dtype=torch.int64, device=dev)
+    iters = 4000
+    st = _ops.new_rng_state(5, dev)
+    loss3 = torch.zeros(3, device=dev)
+    dummy = torch.zeros(n, 3, device=dev)
+    for it in range(iters):
+        rays, target, pix = _ops.select_rays_draw(h, w, cams, view, 2.0, 6.0, st, n, images, want_pixels=True)
+        if it < 3:
+            assert len(torch.unique(pix)) == n
+            ref_rays, ref_target = _ops.select_rays_indirect(h, w, cams, view, 2.0, 6.0, pix, images)
+            assert torch.equal(rays, ref_rays) and torch.equal(target, ref_target)
+        counts += torch.bincount(pix, minlength=h * w)
+        _ops.mse2_loss(dummy, dummy, dummy, rng_state=st)          # what advances the iteration counter in a training loop
+    assert st.tolist()[3] == iters and int(counts.sum()) == iters * n
+    expect = iters * n / (h * w)
+    # sampling without replacement: variance of a pixel's count = iters * p (1 - p), p = n / (H W)
+    p = n / (h * w)
+    chi2 = float(((counts.double() - expect) ** 2).sum() / (iters * p * (1 - p)))
+    dof = h * w - 1
+    assert abs(chi2 - dof) < 5.0 * (2 * dof) ** 0.5, (chi2, dof)
+    assert int(counts.min()) > 0.8 * expect and int(counts.max()) < 1.2 * expect
+
+
+def test_in_kernel_uniforms_and_normals(dev):
+    """The jitter / resampling uniforms and the density-noise normals the training kernels draw themselves (Philox-4x32-10 + Box-
+    Muller, csrc/dn_rng.h; reference: torch.rand / torch.randn, nerf/train_utils.py:126-133, volume_rendering_utils.py:32-38):
+    moments, range, independence across streams and iterations, reproducibility."""
+    from nerf import _ops
+    st = _ops.new_rng_state(123, dev)
+    n = 1 << 20
+    u = _ops.rng_fill(st, 0, (n,)).double()
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0
+    assert abs(float(u.mean()) - 0.5) < 4 * (1 / 12 / n) ** 0.5 and abs(float(u.var()) - 1 / 12) < 1e-3
+    hist = torch.histc(u.float(), bins=64, min=0.0, max=1.0).double()
+    chi2 = float(((hist - n / 64) ** 2 / (n / 64)).sum())
+    assert abs(chi2 - 63) < 5 * (2 * 63) ** 0.5, chi2
+    z = _ops.rng_fill(st, 1, (n,), normal=True).double()
+    assert bool(torch.isfinite(z).all())
+    assert abs(float(z.mean())) < 4 / n ** 0.5 and abs(float(z.var()) - 1.0) < 5e-3
+    assert abs(float((z ** 3).mean())) < 2e-2 and abs(float((z ** 4).mean()) - 3.0) < 5e-2
+    assert abs(float((z.abs() > 3).double().mean()) - 0.0027) < 5e-4
+    u2 = _ops.rng_fill(st, 2, (n,)).double()
+    assert abs(float(((u - 0.5) * (u2 - 0.5)).mean())) < 4 / 12 / n ** 0.5          # streams are uncorrelated
+    assert abs(float(((u[:-1] - 0.5) * (u[1:] - 0.5)).mean())) < 4 / 12 / n ** 0.5   # and so are neighbours
+    assert torch.equal(_ops.rng_fill(_ops.new_rng_state(123, dev), 0, (n,)).double(), u)
+    u_next = _ops.rng_fill(_ops.new_rng_state(123, dev, first_iteration=1), 0, (n,)).double()
+    assert not torch.equal(u_next, u) and abs(float(((u - 0.5) * (u_next - 0.5)).mean())) < 4 / 12 / n ** 0.5
+
+
+@pytest.mark.parametrize("precision,luminance", [("fp32", False), ("bf16-s8", False), ("fp32", True)])
+def test_fused_train_step_equals_the_autograd_path_on_the_same_draws(dev, precision, luminance, monkeypatch):
+    """nerf.FusedTrainStep (device pixel draw, in-kernel jitter / u / density noise, dn_mse2_loss, no autograd graph) against
+    predict_and_render_radiance under autograd + torch's mse_loss fed the SAME pixels and the SAME draws (read back with dn_rng_fill):
+    the six maps bit for bit, the loss and both MSEs to fp32 rounding, the parameter gradients of both networks to the reordering
+    noise of the weight-gradient kernel's atomics; and the iteration counter advances exactly once per step."""
+    import nerf
+    from nerf import _ops, parallel, synthetic as syn
+    h, w, n = 40, 52, 512
+    mkw = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+    cfg = make_cfg(dict(num_coarse=64, num_fine=64, near=2.0, far=6.0, perturb=True, noise_std=0.2, white_background=True), chunksize=4096)
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    poses = [torch.from_numpy(syn.scene_pose(k)) for k in (3, 9)]
+    kmat = torch.from_numpy(syn.intrinsic(h, w))
+    images = torch.rand(2, h, w, 3, device=dev)
+    nerf.set_precision(precision)
+    try:
+        def models():
+            return make_models(mkw, syn.synth_state_dict(21, sigma_bias=-1.0, **mkw), syn.synth_state_dict(22, sigma_bias=-1.0, **mkw), dev)
+        sel = nerf.MultiViewRaySelector(h, w, poses, [kmat, kmat], 2.0, 6.0, images=images, device=dev)
+        sel.view.fill_(1)
+        mc, mf = models()
+        bucket = parallel.FlatGradBucket([mc, mf])
+        step = nerf.FusedTrainStep(mc, mf, sel, cfg, bucket, ex, ed, n, seed=77, luminance=luminance, first_iteration=5)
+        # what the kernels will draw in iteration 5
+        peek = _ops.new_rng_state(77, dev, 5)
+        rays_ref, target_ref, pix = _ops.select_rays_draw(h, w, sel.cams, sel.view, 2.0, 6.0, peek, n, images, want_pixels=True)
+        draws = [_ops.rng_fill(peek, 0, (n, 64)), _ops.rng_fill(peek, 1, (n, 64), normal=True), _ops.rng_fill(peek, 2, (n, 64)),
+                 _ops.rng_fill(peek, 3, (n, 128), normal=True)]
+        loss3 = step.forward_backward()
+        assert step.rng_state.tolist()[2:] == [5, 6]
+        grads_fused = [p.grad.detach().clone() for p in bucket.params]
+        maps_fused = step._keep[2]
+        # the autograd path on the same rays and draws
+        mc2, mf2 = models()
+        q_rand, q_randn = [draws[0], draws[2]], [draws[1], draws[3]]
+        monkeypatch.setattr(torch, "rand", lambda *a, **k: q_rand.pop(0))
+        monkeypatch.setattr(torch, "randn", lambda *a, **k: q_randn.pop(0))
+        out = nerf.predict_and_render_radiance(rays_ref, mc2, mf2, cfg, mode="train", encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=None)
+        monkeypatch.undo()
+        assert not q_rand and not q_randn
+        for a, b in zip(maps_fused[:6], out[:6]):
+            assert torch.equal(a, b.detach())
+
+        def head(t):
+            return (0.299 * t[..., 0] + 0.587 * t[..., 1] + 0.114 * t[..., 2]) if luminance else t
+        mse_c, mse_f = nerf.img2mse(head(out[0]), head(target_ref)), nerf.img2mse(head(out[3]), head(target_ref))
+        (mse_c + mse_f).backward()
+        got = loss3.tolist()
+        assert abs(got[1] - mse_c.item()) < 1e-5 * abs(mse_c.item()) and abs(got[2] - mse_f.item()) < 1e-5 * abs(mse_f.item())
+        assert abs(got[0] - (mse_c + mse_f).item()) < 1e-5 * abs((mse_c + mse_f).item())
+        tol = 1e-4 if precision == "fp32" else 2e-3
+        for g, p in zip(grads_fused, list(mc2.parameters()) + list(mf2.parameters())):
+            assert rel_err(C(g), C(p.grad)) < tol, (tuple(g.shape), rel_err(C(g), C(p.grad)))
+        # a second step: new pixels, new draws, counter 6 -> 7
+        step.forward_backward()
+        assert step.rng_state.tolist()[2:] == [6, 7]
+    finally:
+        nerf.set_precision("fp32")
+
+
 # ---- 8-bit saved tensors (DN_PREC_BF16_S8, nerf.set_precision("bf16-s8")) -----------------------------------------------------
 @pytest.mark.parametrize("depth,width,viewdirs,skip", [(8, 256, True, 4), (4, 128, True, 4), (8, 256, False, 3), (5, 128, False, 2), (3, 256, True, 2)])
 def test_s8_training_kernels_in_the_48_point_geometry(dev, depth, width, viewdirs, skip):

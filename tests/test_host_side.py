@@ -58,14 +58,18 @@ def test_argument_validation_needs_no_gpu(hiplib):
     null = None
     assert hiplib.dn_render_rays_train(ctypes.byref(d), null, ctypes.byref(d), null, 1, null, 11, 4, 64, 128, 0, 0.0, 0, None, 0,
                                        null, null, null, null, null, null, null, null, null, null, null, null, null, null,
-                                       null, null, null) == -1000
+                                       null, null, null, 0, null) == -1000
     assert b"dn_render_rays_train" in hiplib.dn_last_error()
     assert hiplib.dn_render_rays_backward(ctypes.byref(d), null, ctypes.byref(d), null, 1, null, 11, 4, 64, 128, 0.0, 0, null, null,
                                           null, null, null, null, null, null, null, null, null, null, null, null, null,
-                                          None, None, None, None, 3, null) == -1000
+                                          None, None, None, None, 3, null, null) == -1000
     assert hiplib.dn_render_rays_train(ctypes.byref(d), null, ctypes.byref(d), null, 1, null, 11, 0, 64, 128, 0, 0.0, 0, None, 0,
                                        null, null, null, null, null, null, null, null, null, null, null, null, null, null,
-                                       null, null, null) == 0     # zero rays: nothing to do
+                                       null, null, null, 0, null) == 0     # zero rays: nothing to do
+    # the device-side draws of a training iteration: argument checks (no launch without a GPU)
+    assert hiplib.dn_select_rays_draw(4, 4, null, null, 2.0, 6.0, null, 4, null, 0, null, null, null, null) == -1000
+    assert hiplib.dn_mse2_loss(null, null, null, 4, 0, null, null, null, null, null) == -1000
+    assert hiplib.dn_rng_fill(null, 0, 4, 0, null, null) == -1000 and hiplib.dn_rng_fill(null, 0, 0, 0, null, null) == 0
     # 8-bit saved tensors (DN_PREC_BF16_S8): the same tiles at one 1 KiB unit per PAIR of bf16 pieces; bf16 arithmetic only
     d.hidden_size = 256
     sizes = {}

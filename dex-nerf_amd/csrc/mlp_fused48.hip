@@ -500,7 +500,23 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 
 // ---- pack: nn.Linear tensors -> bias rows + encoding tables + 16x32 A pieces -----------------------------------
 template <int F>
+__device__ __forceinline__ void pack48_body(const NetLayout& L, const PackPtrs& ptrs, const G48Tables& tabs, char* __restrict__ region);
+
+template <int F>
 __global__ void pack48_kernel(NetLayout L, PackPtrs ptrs, G48Tables tabs, char* __restrict__ region) {
+  pack48_body<F>(L, ptrs, tabs, region);
+}
+
+// two networks of one architecture (the coarse and the fine net of a training step) in one launch: blockIdx.y picks the net
+template <int F>
+__global__ void pack48_pair_kernel(NetLayout L, PackPtrs ptrs_a, PackPtrs ptrs_b, G48Tables tabs, char* __restrict__ region_a,
+                                   char* __restrict__ region_b) {
+  if (blockIdx.y == 0) pack48_body<F>(L, ptrs_a, tabs, region_a);
+  else pack48_body<F>(L, ptrs_b, tabs, region_b);
+}
+
+template <int F>
+__device__ __forceinline__ void pack48_body(const NetLayout& L, const PackPtrs& ptrs, const G48Tables& tabs, char* __restrict__ region) {
   using Elem = typename Prec<F>::Elem;
   const int n_rows = L.total_bias_tiles * 16;
   float* bias_out = reinterpret_cast<float*>(region);
@@ -599,6 +615,18 @@ bool g48_range_guard_complete(const dn_mlp_desc& d) {
   build_layout48(d, &L);
   const bool paper = d.hidden_size == 256 && d.num_layers == 8 && L.skip_mask == 0x10u && d.use_viewdirs;
   return paper || d.hidden_size == 128;
+}
+
+int launch_pack48_pair(const dn_mlp_desc& d, const PackPtrs& a, const PackPtrs& b, char* region_a, char* region_b, hipStream_t stream) {
+  NetLayout L;
+  build_layout48(d, &L);
+  G48Tables tabs{};
+  fill_freqs(tabs.fx, d.num_encoding_fn_xyz, d.log_sampling_xyz);
+  if (d.use_viewdirs) fill_freqs(tabs.fd, d.num_encoding_fn_dir, d.log_sampling_dir);
+  tabs.LX = d.num_encoding_fn_xyz; tabs.LD = d.num_encoding_fn_dir;
+  static_assert(sizeof(NetLayout) + 2 * sizeof(PackPtrs) + sizeof(G48Tables) + 16 <= 4096, "kernel arguments of the pair pack");
+  hipLaunchKernelGGL(pack48_pair_kernel<1>, dim3(256, 2), dim3(256), 0, stream, L, a, b, tabs, region_a, region_b);
+  return check_launch("mlp_pack48_pair");
 }
 
 int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in, const char* region, hipStream_t stream) {

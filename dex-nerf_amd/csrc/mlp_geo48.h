@@ -216,6 +216,8 @@ int backward48_entry(const dn_mlp_desc* desc, const void* packed_bwd, const floa
                      void* grads, float grad_scale, hipStream_t stream);                                  // mlp_train48.hip
 int unpack48_entry(const dn_mlp_desc* desc, int which, const void* native, int64_t n_points, int slot, int width, int kind, float* out,
                    int ld_out, int col0, float grad_scale, hipStream_t stream);                             // mlp_train48.hip
+int launch_pack48_pair(const dn_mlp_desc& d, const PackPtrs& a, const PackPtrs& b, char* region_a, char* region_b, hipStream_t stream);
+int launch_pack48_backward_pair(const dn_mlp_desc& d, const PackPtrs& a, const PackPtrs& b, char* packed_a, char* packed_b, hipStream_t stream);
 int launch_pack48_backward(const dn_mlp_desc& d, const PackPtrs& ptrs, char* packed, hipStream_t stream);   // mlp_train48.hip
 
 }  // namespace dn

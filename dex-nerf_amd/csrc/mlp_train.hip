@@ -370,6 +370,30 @@ extern "C" int dn_mlp_pack_backward(const dn_mlp_desc* desc, int precision, cons
   return launch_pack(L, ptrs, packed, precision, as_stream(stream));
 }
 
+// Both streams a DN_PREC_BF16_S8 training step reads - the 48-point forward stream (inside `packed`, behind the core one) and the
+// transposed backward stream - for TWO networks of one architecture (the coarse and the fine net), in two launches instead of four.
+extern "C" int dn_mlp_pack_train_pair(const dn_mlp_desc* desc, const float* const* h_weights_a, const float* const* h_biases_a,
+                                      void* packed_a, void* packed_bwd_a, const float* const* h_weights_b,
+                                      const float* const* h_biases_b, void* packed_b, void* packed_bwd_b, dn_stream_t stream) {
+  int rc = validate_desc(desc, DN_PREC_BF16);
+  if (rc) return rc;
+  DN_REQUIRE(g48_train_supported(*desc), "dn_mlp_pack_train_pair: no 8-bit-saved-tensor training kernels for this network");
+  DN_REQUIRE(h_weights_a && h_biases_a && packed_a && packed_bwd_a && h_weights_b && h_biases_b && packed_b && packed_bwd_b,
+             "dn_mlp_pack_train_pair: NULL pointer");
+  const int n_params = desc->num_layers + (desc->use_viewdirs ? 4 : 1);
+  PackPtrs a{}, b{};
+  for (int i = 0; i < n_params; ++i) {
+    DN_REQUIRE(h_weights_a[i] && h_biases_a[i] && h_weights_b[i] && h_biases_b[i], "dn_mlp_pack_train_pair: parameter %d is NULL", i);
+    a.w[i] = h_weights_a[i]; a.b[i] = h_biases_a[i];
+    b.w[i] = h_weights_b[i]; b.b[i] = h_biases_b[i];
+  }
+  NetLayout L;
+  build_layout(*desc, DN_PREC_BF16, &L);   // the 48-point region starts behind the core stream
+  const size_t core = static_cast<size_t>(L.bias_bytes) + static_cast<size_t>(L.total_pieces) * kPieceBytes;
+  if ((rc = launch_pack48_pair(*desc, a, b, static_cast<char*>(packed_a) + core, static_cast<char*>(packed_b) + core, as_stream(stream)))) return rc;
+  return launch_pack48_backward_pair(*desc, a, b, static_cast<char*>(packed_bwd_a), static_cast<char*>(packed_bwd_b), as_stream(stream));
+}
+
 extern "C" int dn_run_network_train(const dn_mlp_desc* desc, int precision, const void* packed, const float* pts,
                                     const float* viewdirs, const float* rays, int ray_stride, const float* z_vals,
                                     int64_t n_rays, int samples_per_ray, float* out, void* act, void* masks,

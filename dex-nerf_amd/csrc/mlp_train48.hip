@@ -296,7 +296,17 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
 }
 
 // ---- pack: nn.Linear tensors -> the transposed 16 x 32 A pieces of build_backward_layout48 ------------------------------
-__global__ void pack48_backward_kernel(NetLayout L, PackPtrs ptrs, char* __restrict__ out) {
+__device__ __forceinline__ void pack48_backward_body(const NetLayout& L, const PackPtrs& ptrs, char* __restrict__ out);
+
+__global__ void pack48_backward_kernel(NetLayout L, PackPtrs ptrs, char* __restrict__ out) { pack48_backward_body(L, ptrs, out); }
+
+// two networks of one architecture in one launch (blockIdx.y picks the net)
+__global__ void pack48_backward_pair_kernel(NetLayout L, PackPtrs ptrs_a, PackPtrs ptrs_b, char* __restrict__ out_a, char* __restrict__ out_b) {
+  if (blockIdx.y == 0) pack48_backward_body(L, ptrs_a, out_a);
+  else pack48_backward_body(L, ptrs_b, out_b);
+}
+
+__device__ __forceinline__ void pack48_backward_body(const NetLayout& L, const PackPtrs& ptrs, char* __restrict__ out) {
   __bf16* wout = reinterpret_cast<__bf16*>(out);
   const long long n_elems = static_cast<long long>(L.total_pieces) * 64 * 8;
   for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < n_elems;
@@ -381,6 +391,13 @@ int launch_pack48_backward(const dn_mlp_desc& d, const PackPtrs& ptrs, char* pac
   build_backward_layout48(d, &L);
   hipLaunchKernelGGL(pack48_backward_kernel, dim3(512), dim3(256), 0, stream, L, ptrs, packed);
   return check_launch("mlp_pack48_backward");
+}
+
+int launch_pack48_backward_pair(const dn_mlp_desc& d, const PackPtrs& a, const PackPtrs& b, char* packed_a, char* packed_b, hipStream_t stream) {
+  NetLayout L;
+  build_backward_layout48(d, &L);
+  hipLaunchKernelGGL(pack48_backward_pair_kernel, dim3(256, 2), dim3(256), 0, stream, L, a, b, packed_a, packed_b);
+  return check_launch("mlp_pack48_backward_pair");
 }
 
 int launch_backward48(const dn_mlp_desc& d, Bwd48Params p, hipStream_t stream) {

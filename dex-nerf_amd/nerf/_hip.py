@@ -27,7 +27,7 @@ EXPORTS = (
     "dn_mlp_backward_data", "dn_mlp_unpack", "dn_mlp_weight_grad", "dn_mlp_weight_grad_all",
     "dn_select_rays", "dn_select_rays_indirect", "dn_ndc_rays", "dn_dex_error_sweep", "dn_depth_error_image",
     "dn_render_train_workspace_bytes", "dn_render_rays_train", "dn_render_rays_backward",
-    "dn_set_s8_grad_scale", "dn_mlp_pack_parts", "dn_fp16_range_guard", "dn_select_rays_draw", "dn_mse2_loss", "dn_rng_fill",
+    "dn_set_s8_grad_scale", "dn_mlp_pack_parts", "dn_fp16_range_guard", "dn_select_rays_draw", "dn_mse2_loss", "dn_rng_fill", "dn_mlp_pack_train_pair",
 )
 
 
@@ -95,6 +95,8 @@ def _declare(lib):
     lib.dn_select_rays_draw.argtypes = [c_int, c_int, fp, vp, c_float, c_float, vp, c_int64, fp, c_int, fp, fp, vp, vp]
     lib.dn_mse2_loss.argtypes = [fp, fp, fp, c_int64, c_int, fp, fp, fp, vp, vp]
     lib.dn_rng_fill.argtypes = [vp, ctypes.c_uint32, c_int64, c_int, fp, vp]
+    lib.dn_mlp_pack_train_pair.argtypes = [POINTER(MlpDesc), POINTER(c_void_p), POINTER(c_void_p), vp, vp, POINTER(c_void_p), POINTER(c_void_p),
+                                           vp, vp, vp]
     for name in EXPORTS:
         if name not in ("dn_last_error", "dn_mlp_packed_bytes", "dn_render_workspace_bytes",
                         "dn_mlp_backward_packed_bytes", "dn_render_train_workspace_bytes"):

@@ -293,6 +293,45 @@ def ensure_backward_stream(model, packed, prec=None):
     return packed.buffers_bwd[prec]
 
 
+def pack_train_pair(model_a, model_b, logs):
+    """The streams a DN_PREC_BF16_S8 training step reads, for two networks of one architecture, in two launches (dn_mlp_pack_train_pair)
+    - or, when that does not apply (different shapes, another precision, nothing stale), the per-network route.  Returns the two
+    packed networks and the precision code."""
+    pa, pb = model_a._packed_slot(*logs), model_b._packed_slot(*logs)
+    prec = train_precision(pa)
+    capturing = torch.cuda.is_current_stream_capturing()
+    same = bytes(pa.desc) == bytes(pb.desc) and train_precision(pb) == prec == _hip.PREC_BF16_S8
+    ka, kb = model_a.param_key(), model_b.param_key()
+    stale = lambda pk, key: pk.key48 != key or pk.keys_bwd.get(prec) != key   # noqa: E731
+    if same and (capturing or (stale(pa, ka) and stale(pb, kb))):
+        for pk in (pa, pb):
+            if pk.buffers_bwd.get(prec) is None:
+                pk.buffers_bwd[prec] = torch.empty(lib().dn_mlp_backward_packed_bytes(ctypes.byref(pk.desc), prec), dtype=torch.uint8,
+                                                   device=pk.buffer.device)
+        arrays, keep = [], []
+        for model in (model_a, model_b):
+            mods = model.linear_modules()
+            ws = [f32c(m.weight.detach()) for m in mods]
+            bs = [f32c(m.bias.detach()) for m in mods]
+            keep.append((ws, bs))
+            arrays.append(((c_void_p * len(ws))(*[w.data_ptr() for w in ws]), (c_void_p * len(bs))(*[b.data_ptr() for b in bs])))
+        check(lib().dn_mlp_pack_train_pair(ctypes.byref(pa.desc), arrays[0][0], arrays[0][1], ptr(pa.buffer), ptr(pa.buffers_bwd[prec]),
+                                           arrays[1][0], arrays[1][1], ptr(pb.buffer), ptr(pb.buffers_bwd[prec]), stream()),
+              "dn_mlp_pack_train_pair")
+        pa._keep_pair = keep
+        for pk, key in ((pa, ka), (pb, kb)):
+            pk.key48 = key
+            pk.keys_bwd[prec] = key
+        return pa, pb, prec
+    pa, pb = model_a.packed(*logs, train=True), model_b.packed(*logs, train=True)
+    prec = train_precision(pa)
+    if train_precision(pb) != prec:
+        prec = pa.precision
+    ensure_backward_stream(model_a, pa, prec)
+    ensure_backward_stream(model_b, pb, prec)
+    return pa, pb, prec
+
+
 def s8_supported(packed):
     """True when the 8-bit-saved-tensor training kernels (48-point geometry) cover this network."""
     return lib().dn_mlp_backward_packed_bytes(ctypes.byref(packed.desc), _hip.PREC_BF16_S8) != 0

@@ -52,12 +52,7 @@ class FusedTrainStep:
         sel = self.selector
         rays, target = _ops.select_rays_draw(sel.height, sel.width, sel.cams, sel.view, sel.near, sel.far, self.rng_state, self.num_rays,
                                              sel.images)
-        pc, pf = mc.packed(*self.logs, train=True), mf.packed(*self.logs, train=True)
-        prec = _ops.train_precision(pc)
-        if _ops.train_precision(pf) != prec:
-            prec = pc.precision
-        _ops.ensure_backward_stream(mc, pc, prec)
-        _ops.ensure_backward_stream(mf, pf, prec)
+        pc, pf, prec = _ops.pack_train_pair(mc, mf, self.logs)
         maps, saved = _ops.render_rays_train(pc, pf, rays, self.nc, self.nf, self.lindisp, self.noise_std, self.white, [], None, prec=prec,
                                              rng_state=self.rng_state, perturb=self.perturb)
         self.loss3, g_c, g_f = _ops.mse2_loss(maps[0], maps[3], target, self.luminance, self.rng_state)

@@ -94,12 +94,8 @@ class FlexibleNeRFModel(torch.nn.Module):
         mods = self.linear_modules()
         dev = mods[0].weight.device
         prec = _ops._precision if precision is None else precision   # (a render may ask for fp16 beside the bf16 training pack)
-        slot = (prec, bool(log_sampling_xyz), bool(log_sampling_dir), dev)
         key = self.param_key()
-        pk = self._packed.get(slot)
-        if pk is None:
-            pk = _ops.PackedMLP(self.desc_kwargs(log_sampling_xyz, log_sampling_dir), dev, prec)
-            self._packed[slot] = pk
+        pk = self._packed_slot(log_sampling_xyz, log_sampling_dir, prec)
         # under stream capture always (re)pack: a captured graph must contain the pack of the weights it runs on, whatever
         # the host-side cache believes at capture time
         capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
@@ -120,6 +116,17 @@ class FlexibleNeRFModel(torch.nn.Module):
                 pk.key = key
             if parts & _hip.PACK_G48:
                 pk.key48 = key
+        return pk
+
+    def _packed_slot(self, log_sampling_xyz=True, log_sampling_dir=True, precision=None):
+        """The PackedMLP object of (precision, sampling flags, device), created empty on first use (packed() fills it)."""
+        dev = self.layer1.weight.device
+        prec = _ops._precision if precision is None else precision
+        slot = (prec, bool(log_sampling_xyz), bool(log_sampling_dir), dev)
+        pk = self._packed.get(slot)
+        if pk is None:
+            pk = _ops.PackedMLP(self.desc_kwargs(log_sampling_xyz, log_sampling_dir), dev, prec)
+            self._packed[slot] = pk
         return pk
 
     def fused_ok(self):

@@ -235,10 +235,9 @@ def main(argv=None):
     def iteration():
         """select rays -> coarse + fine render -> loss -> backward -> (all-reduce) -> Adam; device-side state only."""
         if fused is not None:
-            loss3 = fused.forward_backward()
+            fused.forward_backward()     # (the loss stays in fused.loss3: read where it is logged)
             bucket.all_reduce_mean()
             opt.step()
-            loss_t.copy_(loss3[0])
             return
         rays, target = selector.select(selector.random_pixels(args.num_random_rays))
         if args.ndc:
@@ -291,7 +290,7 @@ def main(argv=None):
         else:
             iteration()
         if it % 100 == 0 or it == args.iters - 1:
-            loss_val = loss_t.item()
+            loss_val = (fused.loss3[0] if fused is not None else loss_t).item()
             psnr = nerf.mse2psnr(loss_val)
             history.append((it, loss_val, psnr))
             if rank == 0 and not args.quiet:

@@ -172,17 +172,15 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pos
     bucket = parallel.FlatGradBucket(models)
     opt = torch.optim.Adam(bucket.params, lr=5e-4, fused=True)  # one multi-tensor kernel instead of seven
     from nerf import synthetic as syn
-    image = torch.rand(H, W, 3, device=dev)
-    selector = nerf.RaySelector(H, W, torch.from_numpy(syn.scene_pose(pose_id)), torch.from_numpy(syn.intrinsic(H, W)), 2.0, 6.0, device=dev)
+    image = torch.rand(1, H, W, 3, device=dev)
+    selector = nerf.MultiViewRaySelector(H, W, [torch.from_numpy(syn.scene_pose(pose_id))], [torch.from_numpy(syn.intrinsic(H, W))], 2.0, 6.0,
+                                         images=image, device=dev)
+    # the iteration the build's training driver runs (train_dexnerf.py): device-side pixel draw, the render with its draws made
+    # in the kernels, loss head + upstream gradients in one launch, backward, exchange, fused Adam (nerf.FusedTrainStep)
+    fused = nerf.FusedTrainStep(models[0], models[1], selector, cfg, bucket, ex, ed, n_rays, seed=1234 + pose_id)
 
     def step():
-        # pixel draw -> packed ray rows + target pixels in one kernel, then the reference's per-chunk entry point
-        rays, target = selector.select(selector.random_pixels(n_rays), image)
-        out = nerf.predict_and_render_radiance(rays, models[0], models[1], cfg, mode="train", encode_position_fn=ex,
-                                               encode_direction_fn=ed, m_thres_cand=M_THRES)
-        loss = nerf.img2mse(out[0], target) + nerf.img2mse(out[3], target)
-        bucket.zero()
-        loss.backward()
+        fused.forward_backward()
         bucket.all_reduce_mean()
         opt.step()
     for _ in range(3):
@@ -202,7 +200,7 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pos
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     res = {"rays_per_s": world * n_rays / dt, "ms_per_step": dt * 1e3, "rays_per_step_per_gpu": n_rays, "n_gpus": world,
-           "what": "ray selection + fwd + bwd + fused Adam, 64+128 samples, perturb + noise 0.2, D8/W256 x2, fused HIP training kernels"}
+           "what": "device pixel draw + ray rows + fwd + loss + bwd + fused Adam (nerf.FusedTrainStep), 64+128 samples, perturb + noise 0.2, D8/W256 x2"}
     # roofline of the step: HBM-bound by construction - the saved activations and gradients are written
     # once by the forward / backward chains and read once by the weight-gradient kernel; MFMA rate beside it (3x forward FLOP)
     nbytes = 0

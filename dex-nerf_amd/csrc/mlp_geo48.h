@@ -130,6 +130,17 @@ bool g48_range_guard_complete(const dn_mlp_desc& d);
 //   word 0 = [group 0: lo, hi | group 1: lo, hi], word 1 = [group 2: lo, hi | 0, 0]; bit of accumulator register r of 16-row
 //   tile nt: dword nt / 8, bit ((nt % 8) * 2 + r / 2) + 16 * (r % 2) - i.e. straight from the packed 16-bit ReLU outputs
 //   (v_pk_min_u16(pair, 1) << position) and back onto packed pairs in the backward (((w >> position) & 0x00010001) * 0xFFFF).
+// Behind the saved-gradient units of a launch: a 256-byte record (uint32 words).  The backward-data kernel records the scale it
+// used and zeroes the three statistics words; the weight-gradient kernel (same stream, next) counts into them while it reads the
+// gradients anyway: of the dY bytes of one 32-point record in sixteen, how many are non-zero, how many sit at e5m2's largest
+// magnitude (saturated: the gradient was at or beyond 57344 / scale) and how many at its smallest (the edge of being flushed to
+// zero: below 2^-17 / scale a gradient is lost).
+constexpr int kS8BlockBytes = 256;
+enum { kS8BlockSaturated = 1, kS8BlockFloor = 2, kS8BlockSampled = 3,
+       kS8BlockScale = 4,           // bits of the scale this launch used (the weight-gradient kernel divides it out)
+       kS8BlockPartials = 8,        // auto scale: kS8BlockPartialCount partial maxima of |upstream gradient| (bits)
+       kS8BlockPartialCount = 56 };
+
 struct TrainLayout48 {
   int32_t kh_u;                     // units of a W-wide hidden vector
   int32_t act_units;                // saved forward units per 16-point group
@@ -215,7 +226,7 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p, co
 int backward48_entry(const dn_mlp_desc* desc, const void* packed_bwd, const float* g_out, const void* masks, int64_t n_points,
                      void* grads, float grad_scale, hipStream_t stream);                                  // mlp_train48.hip
 int unpack48_entry(const dn_mlp_desc* desc, int which, const void* native, int64_t n_points, int slot, int width, int kind, float* out,
-                   int ld_out, int col0, float grad_scale, hipStream_t stream);                             // mlp_train48.hip
+                   int ld_out, int col0, hipStream_t stream);                             // mlp_train48.hip
 int launch_pack48_pair(const dn_mlp_desc& d, const PackPtrs& a, const PackPtrs& b, char* region_a, char* region_b, hipStream_t stream);
 int launch_pack48_backward_pair(const dn_mlp_desc& d, const PackPtrs& a, const PackPtrs& b, char* packed_a, char* packed_b, hipStream_t stream);
 int launch_pack48_backward(const dn_mlp_desc& d, const PackPtrs& ptrs, char* packed, hipStream_t stream);   // mlp_train48.hip

@@ -322,7 +322,7 @@ extern "C" int dn_mlp_train_sizes(const dn_mlp_desc* desc, int precision, int64_
     const size_t records = static_cast<size_t>(g48_padded_records(n_points));
     *act_bytes = records * 2 * t8.act_units * kPieceBytes;
     *mask_bytes = records / (kG48PointsPerWg / 32) * kG48Waves * t8.mask_stages * 2 * kPieceBytes;
-    *grad_bytes = records * 2 * t8.grad_units * kPieceBytes;
+    *grad_bytes = records * 2 * t8.grad_units * kPieceBytes + kS8BlockBytes;   // + the statistics / scale record (mlp_geo48.h)
     return 0;
   }
   TrainLayout t;
@@ -485,7 +485,7 @@ extern "C" int dn_mlp_unpack(const dn_mlp_desc* desc, int precision, int which, 
     DN_REQUIRE(native && out && n_points >= 0 && width > 0 && ld_out >= col0 + 1 && (which == 0 || which == 1) && kind >= 0 && kind <= 3 &&
                g48_train_supported(*desc), "dn_mlp_unpack (8-bit layout): bad arguments");
     if (n_points == 0) return 0;
-    return unpack48_entry(desc, which, native, n_points, slot, width, kind, out, ld_out, col0, g_s8_grad_scale.load(), as_stream(stream));
+    return unpack48_entry(desc, which, native, n_points, slot, width, kind, out, ld_out, col0, as_stream(stream));
   }
   int rc = validate_desc(desc, precision);
   if (rc) return rc;
@@ -552,7 +552,8 @@ struct WgParams {
   // side); dy_odd = which half of its unit a custom dY piece is; out_scale = 1 / (the power of two the gradients were
   // multiplied by before they were rounded to e5m2)
   int dy_odd;
-  float out_scale;
+  const unsigned* scale_word;     // bits of the scale the backward-data launch recorded behind the saved gradients (kS8BlockScale)
+  unsigned* stats_block;          // that record: the 8-bit kernel counts saturated / floor-level gradient bytes into it (mlp_geo48.h)
 #ifdef DN_WG_STAMP
   unsigned long long* stamp;      // diagnostic build: [workgroup][wave][8] accumulated s_memtime ticks
 #endif
@@ -741,6 +742,7 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
   for (int k = 0; k < S::J; ++k)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+  unsigned s8_stats[3] = {0u, 0u, 0u};   // (8-bit kernel) saturated / floor-level / non-zero gradient bytes this lane counted
   bf16x8 ones, zeros;
 #pragma unroll
   for (int e = 0; e < 8; ++e) { ones[e] = static_cast<__bf16>(1.0f); zeros[e] = static_cast<__bf16>(0.0f); }
@@ -819,6 +821,18 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
     // A = dY^T (fragment row 16 fs + li = lane group 2 (ntile % 2) + fs, byte li of the unit row: piece li >> 3, element li & 7)
     i32x8 av = read32(frag_at(0, S::CUSTOM ? 0 : ntile));
     const long long mine = hh ? tile1 : tile0;
+    // statistics of the saved gradients (mlp_geo48.h): every dY byte of a record is in exactly one lane of the waves with k-group
+    // 0; one record in sixteen is counted - byte-parallel compares on the operand registers, this kernel has the issue slots
+    if (kgroup == 0 && (mine & 15) == 0 && mine < tiles) {
+      auto zero_bytes = [](unsigned x) { return __builtin_popcount(((x - 0x01010101u) & ~x & 0x80808080u)); };   // (exact for our inputs: no byte borrows past a zero byte)
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const unsigned mag = static_cast<unsigned>(av[d]) & 0x7F7F7F7Fu;
+        s8_stats[0] += static_cast<unsigned>(zero_bytes(mag ^ 0x7B7B7B7Bu));
+        s8_stats[1] += static_cast<unsigned>(zero_bytes(mag ^ 0x01010101u));
+        s8_stats[2] += 4u - static_cast<unsigned>(zero_bytes(mag));
+      }
+    }
     // points of this lane's tile that exist (the rest: padding copies, or a re-load standing in for an absent tile); a custom dY
     // is piece dy_odd of its unit: the columns of the other piece are not its rows
     int valid = mine < tiles ? static_cast<int>(p.n_points - mine * 32 < 32 ? p.n_points - mine * 32 : 32) : 0;
@@ -1023,6 +1037,15 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
     }
   }
   wait_vmcnt<0>();  // the trailing re-loads
+  float out_scale = 1.0f;
+  if constexpr (S::S8) {
+    out_scale = 1.0f / __uint_as_float(*p.scale_word);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const unsigned tot = static_cast<unsigned>(wave_sum(static_cast<double>(s8_stats[k])));
+      if (lane == 0 && tot != 0u) atomicAdd(p.stats_block + kS8BlockSaturated + k, tot);
+    }
+  }
   // ---- add this workgroup's partial: D[i][j] sits in lane (j = lane&31, half = lane>>5), register r, i = acc_row(r, half)
   const int jl = lane & 31, half = lane >> 5;
   static_for<S::J>([&](auto j_c) {
@@ -1065,7 +1088,7 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
 #if DN_WG_EPI == 1
         if (col >= 0 && acc[j][r] == 1.2345f) p.dW[static_cast<long long>(n) * p.ldw + col] = 1.0f;
 #else
-        const float val = S::S8 ? acc[j][r] * p.out_scale : acc[j][r];
+        const float val = S::S8 ? acc[j][r] * out_scale : acc[j][r];
         if (col >= 0) atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col, val);
         else if (col == -2 && p.db != nullptr) atomicAdd(p.db + n, val);
 #endif
@@ -1388,7 +1411,9 @@ static int wg_fill(const dn_mlp_desc* desc, const TrainLayout& t, const void* ac
     p.dy_odd = p.g_slot & 1;
     p.g_slot /= 2; p.x_slot /= 2; p.pe_slot /= 2;
     p.act_pieces = (t.act_pieces + 1) / 2; p.grad_pieces = (t.grad_pieces + 1) / 2;
-    p.out_scale = 1.0f / g_s8_grad_scale.load();
+    p.stats_block = reinterpret_cast<unsigned*>(const_cast<char*>(static_cast<const char*>(grads)) +
+                                                g48_padded_records(n_points) * 2 * (t.grad_pieces / 4) * kPieceBytes);
+    p.scale_word = p.stats_block + kS8BlockScale;
   }
   *out = p;
   return 0;
@@ -1560,8 +1585,8 @@ extern "C" int dn_mlp_weight_grad(const dn_mlp_desc* desc, int precision, const 
 
 extern "C" int dn_set_s8_grad_scale(float scale) {
   int e = 0;
-  DN_REQUIRE(scale > 0.0f && std::isfinite(scale) && std::frexp(scale, &e) == 0.5f,
-             "dn_set_s8_grad_scale: the scale must be a power of two (the scaling and its inverse are then exact)");
+  DN_REQUIRE(scale == 0.0f || (scale > 0.0f && std::isfinite(scale) && std::frexp(scale, &e) == 0.5f),
+             "dn_set_s8_grad_scale: the scale must be a power of two (the scaling and its inverse are then exact), or 0 = chosen per launch from the largest upstream gradient");
   g_s8_grad_scale.store(scale);
   return 0;
 }

@@ -26,10 +26,11 @@ struct Bwd48Params {
   char* grads;             // saved gradients, s8-48 units
   int grad_units;
   int gslot_dirout, gslot_feat, gslot_trunk0, gslot_layer1, gslot_out;
-  float inv_scale;         // 1 / (the power of two the gradients are multiplied by before they are rounded to e5m2)
-  float clamp_hi, clamp_lo;   // +-57344 / scale: a gradient beyond saturates (e5m2 has infinities; the converts do not saturate).  Two
-                              // parameters, not one negated in the kernel: CodeGenPrepare sinks a copy of the (free) fneg to each of its
-                              // thousands of uses in the unrolled tile pass and takes ten minutes over it
+  float scale;             // the power of two the gradients are multiplied by before they are rounded to e5m2 (auto_scale: unused)
+  int auto_scale;          // pick the scale from the largest |upstream gradient| (block[0], formed by absmax_kernel before this launch)
+  unsigned* block;         // the 256-byte record behind the saved gradients (kS8Block*): statistics + the scale that was used
+  // (the saturation bounds +-57344 / scale are formed once at the top of the kernel, as TWO values - a bound negated at its
+  // uses has CodeGenPrepare sink a copy of the free fneg to each of the thousands of uses in the unrolled tile pass: ten minutes)
 };
 
 constexpr int kBwd48WaveLds = 8 * kPieceBytes;   // per wave: 2 output-gradient slots (1 KiB) + 3 mask-word slots (2 KiB)
@@ -82,6 +83,25 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
   char* wbuf = smem + kRingBytes + wave * kBwd48WaveLds;
   const unsigned wbuf_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)wbuf));
   const int n_masks = FIXED ? (DC - 1) + (VIEWC ? 2 : 0) : p.mask_stages;   // stage q < n_masks applies mask n_masks-1-q; the last stage none
+  // The e5m2 scale of this launch: the caller's power of two, or (auto_scale) the one that puts the largest upstream gradient at
+  // 2^12 - 16x under e5m2's largest value for what the chain may amplify, 2^28 above its smallest subnormal.  Every wave forms the
+  // same number from the same word; one thread records it for the weight-gradient kernel and the statistics reader.
+  float scale = p.scale;
+  if (p.auto_scale) {
+    float gmax = 0.0f;   // the partial maxima absmax_kernel left in the record (words kS8BlockPartials ..; unused ones are zero)
+    for (int i = 0; i < kS8BlockPartialCount; ++i) gmax = fmaxf(gmax, __uint_as_float(p.block[kS8BlockPartials + i]));
+    scale = (gmax > 0.0f && gmax < 3.0e38f) ? exp2f(fminf(fmaxf(12.0f - ceilf(log2f(gmax)), -100.0f), 100.0f)) : 65536.0f;
+  }
+  // (wave-uniform numbers pinned to scalar registers: formed by vector instructions, they would each hold a VGPR for the whole
+  // kernel - this kernel has none to spare)
+  auto uniform_f = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
+  scale = uniform_f(scale);
+  const float inv_scale = uniform_f(1.0f / scale);
+  const float clamp_hi = uniform_f(kE5m2Max * inv_scale), clamp_lo = uniform_f(-kE5m2Max * inv_scale);
+  if (blockIdx.x == 0 && threadIdx.x == 0) p.block[kS8BlockScale] = __float_as_uint(scale);
+  // (the statistics words of the record are zeroed here for the weight-gradient kernel - the next launch on the stream - which
+  // counts saturated / floor-level stores while it reads the gradients anyway)
+  if (blockIdx.x == 0 && threadIdx.x < 3) p.block[kS8BlockSaturated + threadIdx.x] = 0u;
   const int n_points = static_cast<int>(p.n_points);   // (launches of >= 2^31 - 1024 points are refused by the host side)
 
   auto issue_gout = [&](int tile, int slot) {
@@ -135,15 +155,15 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
       typedef short s16x2 __attribute__((ext_vector_type(2)));
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       s16x2 r = {0, 0};
-      r = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(r, __builtin_bit_cast(bf16x2, d0), p.inv_scale, false);
-      r = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(r, __builtin_bit_cast(bf16x2, d1), p.inv_scale, true);
+      r = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(r, __builtin_bit_cast(bf16x2, d0), inv_scale, false);
+      r = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(r, __builtin_bit_cast(bf16x2, d1), inv_scale, true);
       return __builtin_bit_cast(unsigned, r);
     };
     auto save_unit = [&](auto t_c, int slot, const BP8& lo, const BP8& hi) {
       constexpr int t = decltype(t_c)::value;
       const u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
       store16_unit48(grad_grp[t], static_cast<unsigned>(slot) * (2 * kPieceBytes), pipe.lane16,
-                         make_uint4(to_e5m2(a[0], a[1]), to_e5m2(a[2], a[3]), to_e5m2(b[0], b[1]), to_e5m2(b[2], b[3])));
+                     make_uint4(to_e5m2(a[0], a[1]), to_e5m2(a[2], a[3]), to_e5m2(b[0], b[1]), to_e5m2(b[2], b[3])));
     };
 
     // ---- the output gradient of this lane's points: lane group 0 carries it (custom pieces: k = 8 g + e) ----
@@ -157,7 +177,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
         const bool live = (lane < 16) && (pt < n_points);   // padding points (clamped copies in the forward) contribute nothing
         // (saturated like every other gradient of the chain: the custom pieces are stored as e5m2 too)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) gv[t][c] = live ? __builtin_amdgcn_fmed3f(v[c], p.clamp_lo, p.clamp_hi) : 0.0f;
+        for (int c = 0; c < 4; ++c) gv[t][c] = live ? __builtin_amdgcn_fmed3f(v[c], clamp_lo, clamp_hi) : 0.0f;
       }
     }
     // Start of stage q: fetch this stage's mask words from their LDS slot, then stage what will be needed two stages on (same
@@ -184,7 +204,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
     };
     auto emit_to = [&](auto nt_c, auto t_c, const f32x4& acc, auto& bout, int gslot) {
       constexpr int nt = decltype(nt_c)::value, t = decltype(t_c)::value;
-      emit_grad48<nt>(acc, mw[t][0], mw[t][1], p.clamp_lo, p.clamp_hi, bout[t]);
+      emit_grad48<nt>(acc, mw[t][0], mw[t][1], clamp_lo, clamp_hi, bout[t]);
       if constexpr (nt % 4 == 3) save_unit(t_c, gslot + nt / 4, bout[t][nt / 2 - 1], bout[t][nt / 2]);
     };
 
@@ -295,6 +315,19 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
+// largest finite |x| of the upstream gradient: workgroup b (of kS8BlockPartialCount, one wave each) writes ITS maximum to
+// block[kS8BlockPartials + b] - every word is written, nothing needs zeroing first
+__global__ __launch_bounds__(64) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ block) {
+  float m = 0.0f;
+  for (long long i = static_cast<long long>(blockIdx.x) * 64 + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * 64) {
+    const float v = fabsf(x[i]);
+    m = (v < 3.0e38f) ? fmaxf(m, v) : m;   // (a non-finite upstream gradient does not set the scale)
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (threadIdx.x == 0) block[kS8BlockPartials + blockIdx.x] = __float_as_uint(m);
+}
+
 // ---- pack: nn.Linear tensors -> the transposed 16 x 32 A pieces of build_backward_layout48 ------------------------------
 __device__ __forceinline__ void pack48_backward_body(const NetLayout& L, const PackPtrs& ptrs, char* __restrict__ out);
 
@@ -344,7 +377,8 @@ __device__ __forceinline__ void pack48_backward_body(const NetLayout& L, const P
 // which 0: e4m3 activations, 1: e5m2 gradients (x inv_scale).  kind 0: hidden vector, 1 / 2: xyz / view-direction panel,
 // 3: the custom unit (piece 0 elements 0-3 -> columns 0-3, piece 1 elements 0-3 -> columns 4-7: [d rgb . | d alpha . . .]).
 __global__ void unpack48_kernel(const char* __restrict__ buf, int units_per_group, int slot0, int n_units, int kind, int L,
-                                long long n_points, int which, float inv_scale, float* __restrict__ out, int ld_out, int col0) {
+                                long long n_points, int which, const unsigned* __restrict__ block, float* __restrict__ out, int ld_out, int col0) {
+  const float inv_scale = (which == 1) ? 1.0f / __uint_as_float(block[kS8BlockScale]) : 1.0f;   // the scale the backward recorded
   const long long groups = (n_points + 15) / 16;
   const long long total = groups * n_units * 64 * 16;
   for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
@@ -374,7 +408,7 @@ __global__ void unpack48_kernel(const char* __restrict__ buf, int units_per_grou
 }
 
 int unpack48_entry(const dn_mlp_desc* desc, int which, const void* native, int64_t n_points, int slot, int width, int kind, float* out,
-                   int ld_out, int col0, float grad_scale, hipStream_t stream) {
+                   int ld_out, int col0, hipStream_t stream) {
   TrainLayout48 t;
   build_train_layout48(*desc, &t);
   const int per_group = which == 0 ? t.act_units : t.grad_units;
@@ -382,7 +416,9 @@ int unpack48_entry(const dn_mlp_desc* desc, int which, const void* native, int64
   DN_REQUIRE((kind != 0 || width % 64 == 0) && slot >= 0 && slot + n_units <= per_group, "dn_mlp_unpack (8-bit layout): slot range outside the group's units");
   const int L = kind == 1 ? desc->num_encoding_fn_xyz : desc->num_encoding_fn_dir;
   hipLaunchKernelGGL(unpack48_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const char*>(native), per_group, slot, n_units, kind, L,
-                     static_cast<long long>(n_points), which, 1.0f / grad_scale, out, ld_out, col0);
+                     static_cast<long long>(n_points), which,
+                     reinterpret_cast<const unsigned*>(static_cast<const char*>(native) + g48_padded_records(n_points) * 2 * t.grad_units * kPieceBytes),
+                     out, ld_out, col0);
   return check_launch("dn_mlp_unpack");
 }
 
@@ -450,8 +486,13 @@ int dn::backward48_entry(const dn_mlp_desc* desc, const void* packed_bwd, const 
   p.grad_units = t.grad_units;
   p.gslot_dirout = t.gslot_dirout; p.gslot_feat = t.gslot_feat; p.gslot_trunk0 = t.gslot_trunk0; p.gslot_layer1 = t.gslot_layer1;
   p.gslot_out = t.gslot_out;
-  p.inv_scale = 1.0f / grad_scale;
-  p.clamp_hi = kE5m2Max / grad_scale;
-  p.clamp_lo = -p.clamp_hi;
+  // the 256-byte record behind the units (mlp_geo48.h): the largest |upstream gradient| first when the scale is to follow it
+  p.block = reinterpret_cast<unsigned*>(static_cast<char*>(grads) + g48_padded_records(n_points) * 2 * t.grad_units * kPieceBytes);
+  p.auto_scale = grad_scale == 0.0f ? 1 : 0;
+  p.scale = p.auto_scale ? 65536.0f : grad_scale;
+  if (p.auto_scale) {
+    hipLaunchKernelGGL(absmax_kernel, dim3(kS8BlockPartialCount), dim3(64), 0, stream, g_out, static_cast<long long>(n_points) * 4, p.block);
+    if (int rc = check_launch("s8 absmax")) return rc;
+  }
   return launch_backward48(*desc, p, stream);
 }

@@ -83,8 +83,35 @@ def set_s8_grad_scale(scale):
     """Power of two the saved layer gradients are multiplied by before they are rounded to e5m2 (default 65536 = 2^16).
     With it, per-point gradients dL/d(pre-activation) between 2.3e-10 (e5m2's smallest subnormal / 2^16; smaller ones flush to
     zero) and 0.87 (57344 / 2^16; larger ones saturate) are representable, 2 mantissa bits each: the range of a mean-reduced MSE
-    loss over 10^3 .. 10^5 rays from the first iteration to > 40 dB.  A sum-reduced loss, or loss scaling, wants a smaller scale."""
+    loss over 10^3 .. 10^5 rays from the first iteration to > 40 dB.  A sum-reduced loss, or loss scaling, wants a smaller scale -
+    or scale = 0: every backward-data launch then takes the power of two that puts ITS largest upstream gradient at 2^12 (one more
+    small kernel per launch; s8_grad_stats tells whether that is needed)."""
     check(lib().dn_set_s8_grad_scale(float(scale)), "dn_set_s8_grad_scale")
+
+
+S8_RECORD_BYTES = 256     # kS8BlockBytes, csrc/mlp_geo48.h: the record behind the 8-bit saved gradients of a launch
+_s8_records = []          # device views of the records of the latest backward launches (bounded; read by s8_grad_stats)
+
+
+def _note_s8_record(grads, prec):
+    if prec == _hip.PREC_BF16_S8 and grads is not None:
+        _s8_records.append(grads[-S8_RECORD_BYTES:].view(torch.int32))   # (a view: keeps that buffer's storage until two later launches)
+        del _s8_records[:-2]
+
+
+def s8_grad_stats(grads=None):
+    """What the 8-bit saved gradients of the latest training step lost to e5m2's range (include/dexnerf_hip.h, "8-bit saved
+    tensors"): of the sampled non-zero gradient bytes (one 32-point record in sixteen, every layer), the fraction at e5m2's largest
+    magnitude (saturated: clipped at 57344 / scale) and at its smallest (the edge of flushing to zero), plus the scale in use.
+    grads = one saved-gradient buffer, or None = the buffers of the latest backward launches together.  Synchronises (a host
+    read): call it at a logging interval, not every iteration.  None when no 8-bit backward has run."""
+    recs = [grads[-S8_RECORD_BYTES:].view(torch.int32)] if grads is not None else list(_s8_records)
+    if not recs:
+        return None
+    rows = torch.stack([r[:8] for r in recs]).cpu()
+    sat, floor, sampled = (int(rows[:, k].sum()) for k in (1, 2, 3))
+    scales = sorted({float(v) for v in rows[:, 4].contiguous().view(torch.float32).tolist()})
+    return {"saturated": sat / max(sampled, 1), "floor": floor / max(sampled, 1), "sampled": sampled, "scale": scales}
 
 
 def _row_view(t):
@@ -383,6 +410,7 @@ def mlp_backward_data(packed, g_out, masks, n_points, prec=None):
     grads = torch.empty(g_bytes, dtype=torch.uint8, device=g_out.device)
     check(lib().dn_mlp_backward_data(ctypes.byref(packed.desc), prec, ptr(packed.buffers_bwd[prec]), ptr(g_out),
                                      ptr(masks), n_points, ptr(grads), stream()), "dn_mlp_backward_data")
+    _note_s8_record(grads, prec)
     return grads
 
 
@@ -666,4 +694,5 @@ def render_rays_backward(packed_c, packed_f, saved, g_c, g_f, views_c, views_f, 
         ptr(saved["noise_c"]), ptr(saved["noise_f"]), ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]), ptr(gs[5]),
         ptr(saved["ws"]), ptr(saved["act_c"]), ptr(saved["masks_c"]), ptr(grads_c), ptr(saved["act_f"]), ptr(saved["masks_f"]),
         ptr(grads_f), wc, bc, wf, bf, int(nets), ptr(saved.get("rng_state")), stream()), "dn_render_rays_backward")
+    _note_s8_record(grads_c, prec); _note_s8_record(grads_f, prec)
     return grads_c, grads_f   # (kept alive by the caller until the stream has consumed them: PyTorch's caching allocator is stream-ordered)

@@ -134,6 +134,9 @@ def main(argv=None):
     ap.add_argument("--m-thres", type=int, default=100)
     ap.add_argument("--ir", action="store_true", help="IR head of train_nerf_ir.py / train_dexnerf_ir.py: MSE on the luminance "
                                                       "0.299 r + 0.587 g + 0.114 b of prediction and target (:260-263)")
+    ap.add_argument("--s8-grad-scale", type=float, default=None,
+                    help="bf16-s8: power of two the saved layer gradients are scaled by (default 65536); 0 = chosen per launch from the "
+                         "largest upstream gradient (nerf.set_s8_grad_scale)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16-s8", "fp32"],
                     help="bf16-s8: bf16 kernels, the tensors saved for the backward at 8 bits (nerf.set_precision)")
     ap.add_argument("--validate-every", type=int, default=500)
@@ -183,6 +186,9 @@ def main(argv=None):
     np.random.seed(args.seed + rank)          # reference seeds np + torch from cfg.experiment.randomseed (:97-99)
     torch.manual_seed(args.seed + rank)
     nerf.set_precision(args.precision)
+    if args.s8_grad_scale is not None:
+        nerf.set_s8_grad_scale(args.s8_grad_scale)
+    s8_warned, s8_saturated_max = False, 0.0
 
     kw = dict(num_layers=args.layers, hidden_size=args.width, skip_connect_every=4, num_encoding_fn_xyz=10,
               num_encoding_fn_dir=4, use_viewdirs=True)
@@ -296,6 +302,14 @@ def main(argv=None):
             if rank == 0 and not args.quiet:
                 print(f"[train] iter {it:6d} loss {loss_val:.5f} psnr {psnr:.2f} dB lr {lr:.2e} "
                       f"{(time.perf_counter() - t0):.1f} s", flush=True)
+            s8 = nerf.s8_grad_stats() if args.precision == "bf16-s8" else None
+            if s8 is not None:
+                s8_saturated_max = max(s8_saturated_max, s8["saturated"])
+                if s8["saturated"] > 1e-4 and rank == 0 and not s8_warned:
+                    s8_warned = True
+                    print(f"[train] WARNING: {s8['saturated']:.2e} of the 8-bit saved layer gradients are clipped at e5m2's largest value "
+                          f"(scale {s8['scale']}): the loss is outside the range the fixed gradient scale covers (a sum-reduced or "
+                          "scaled loss?) - pass --s8-grad-scale 0 (per-launch scale) or a smaller power of two", flush=True)
         if rank == 0 and args.validate_every and (it + 1) % args.validate_every == 0:
             out = render_view(student, cfg, poses[held_out], intrinsics[held_out], hw, ex, ed, thres)
             vmse = nerf.img2mse(out[3].reshape(-1, 3), images[held_out]).item()
@@ -311,6 +325,8 @@ def main(argv=None):
     elapsed = time.perf_counter() - t0
     result = dict(history=history, final_loss=loss_val, final_psnr=psnr, seconds=elapsed,
                   rays_per_s=world * args.num_random_rays * (args.iters - start) / max(elapsed, 1e-9))
+    if args.precision == "bf16-s8":
+        result["s8_saturated_max"] = s8_saturated_max
     if args.save and rank != 0 and os.environ.get("DEXNERF_SAVE_ALL_RANKS"):   # rehearsals: compare the replicas
         torch.save({"model_coarse_state_dict": student[0].state_dict(), "model_fine_state_dict": student[1].state_dict()}, args.save)
     if rank == 0:

@@ -97,11 +97,17 @@ def lds_read_violations(ins):
     other instruction naming one of those registers in between would read stale data or have its result overwritten.
     Scalar memory loads also count in lgkmcnt and return out of order, so they are tracked as entries without registers
     (they can only make a counted wait retire FEWER of the LDS reads than assumed: a wait with SMEM in flight is treated as
-    retiring nothing unless it is lgkmcnt(0))."""
+    retiring nothing unless it is lgkmcnt(0)).
+    The walk is in layout order: a conditional branch is walked through (its fall-through path), and after an UNCONDITIONAL one
+    (s_branch, s_endpgm, s_setpc_b64) nothing carries over - the next instruction is only reached by jumps, not from the reads
+    above it (the run-time-shape kernels place out-of-line blocks there)."""
     pending = []   # [(dest regs or None for SMEM, text, index)]
     bad = []
     for i, line in enumerate(ins):
         op, ops = split_ins(line)
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            pending = []
+            continue
         if op == "s_waitcnt":
             m = re.search(r"lgkmcnt\((\d+)\)", line)
             if m:

@@ -89,3 +89,4 @@ def test_the_checkers_catch_planted_hazards():
     assert not codeobj.lds_read_violations(stream)
     assert codeobj.lds_read_violations(stream[:2] + ["v_mov_b64_e32 v[30:31], v[12:13]"] + stream[2:])   # the phi copy
     assert codeobj.lds_read_violations(stream[:2] + ["s_waitcnt lgkmcnt(2)"] + stream[3:])               # wait too loose
+    assert not codeobj.lds_read_violations(stream[:2] + ["s_branch 12", "v_mov_b64_e32 v[30:31], v[12:13]"])   # an out-of-line block behind a jump

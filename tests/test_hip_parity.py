@@ -1843,6 +1843,58 @@ def test_s8_training_step_gradients(golden, dev):
     assert cos(whole[2], whole[0]) > 0.99 and cos(whole[2], whole[0]) > cos(whole[1], whole[0]) - 1e-3, (cos(whole[2], whole[0]), cos(whole[1], whole[0]))
 
 
+def test_s8_statistics_and_per_launch_scale_under_a_sum_reduced_loss(dev):
+    """e5m2's range under the fixed scale 2^16 is made for a mean-reduced MSE.  With the SUM-reduced loss (per-point gradients x the
+    number of ray channels) the saved layer gradients clip at 57344 / 2^16: the statistics the weight-gradient kernel counts must
+    say so (this is what train_dexnerf.py warns on), and nerf.set_s8_grad_scale(0) - every backward-data launch takes its scale
+    from its largest upstream gradient - must bring the whole-gradient cosine against the bf16 mode back to >= 0.999."""
+    import nerf
+    from nerf import synthetic as syn
+    mkw = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+    sds = [{k: torch.from_numpy(v) for k, v in syn.synth_state_dict(seed, sigma_bias=-1.0, **mkw).items()} for seed in (41, 43)]
+    cfg = make_cfg(dict(num_coarse=64, num_fine=128, near=2.0, far=6.0, perturb=True, noise_std=0.0))
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    n = 1536
+    gen = torch.Generator().manual_seed(2)
+    ro = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3) + 0.01 * torch.randn(n, 3, generator=gen)
+    rd = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, -1.0]) + 0.3 * torch.randn(n, 3, generator=gen), dim=-1)
+    rays = torch.cat([ro, rd, torch.full((n, 1), 2.0), torch.full((n, 1), 6.0), rd], -1).to(dev)
+    target = torch.rand(n, 3, generator=gen).to(dev)
+
+    def step(prec, reduction, scale=None):
+        nerf.set_precision(prec)
+        if scale is not None:
+            nerf.set_s8_grad_scale(scale)
+        models = []
+        for sd in sds:
+            m = nerf.models.FlexibleNeRFModel(**mkw); m.load_state_dict(sd); models.append(m.to(dev))
+        torch.manual_seed(9)
+        out = nerf.predict_and_render_radiance(rays, models[0], models[1], cfg, mode="train", encode_position_fn=ex,
+                                               encode_direction_fn=ed, m_thres_cand=M_THRES)
+        mse = torch.nn.functional.mse_loss
+        (mse(out[0], target, reduction=reduction) + mse(out[3], target, reduction=reduction)).backward()
+        grad = np.concatenate([C(p.grad).astype(np.float64).reshape(-1) for m in models for p in m.parameters()])
+        return grad, (nerf.s8_grad_stats() if prec == "bf16-s8" else None)
+
+    def cos(a, b):
+        return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+    try:
+        ref_sum, _ = step("bf16", "sum")
+        _, st_mean = step("bf16-s8", "mean", 65536.0)
+        assert st_mean["sampled"] > 10_000 and st_mean["saturated"] == 0.0 and st_mean["scale"] == [65536.0], st_mean
+        g_fixed, st_fixed = step("bf16-s8", "sum", 65536.0)
+        assert st_fixed["saturated"] > 1e-4 and st_fixed["scale"] == [65536.0], st_fixed     # the counter fires ...
+        assert cos(g_fixed, ref_sum) < 0.999, cos(g_fixed, ref_sum)                        # ... and the clipping is real
+        g_auto, st_auto = step("bf16-s8", "sum", 0.0)
+        assert st_auto["saturated"] == 0.0 and all(0.0 < v < 65536.0 and np.log2(v) == round(np.log2(v)) for v in st_auto["scale"]), st_auto
+        assert np.isfinite(g_auto).all() and cos(g_auto, ref_sum) >= 0.999, cos(g_auto, ref_sum)
+        _record_measurement("s8_sum_loss", dict(saturated_fixed=st_fixed["saturated"], cos_fixed=cos(g_fixed, ref_sum),
+                                                cos_auto=cos(g_auto, ref_sum), scale_auto_max=max(st_auto["scale"]), floor_auto=st_auto["floor"]))
+    finally:
+        nerf.set_s8_grad_scale(65536.0)
+        nerf.set_precision("fp32")
+
+
 def test_llff_capture_renders_through_the_ndc_branch(dev, tmp_path):
     """SURVEY 8f N2 + S2b end to end: a forward-facing capture on disk in the LLFF layout -> nerf.load_llff_data -> 4-argument
     get_ray_bundle (camera-to-world convention) -> run_one_iter_of_nerf with dataset.no_ndc = False (near 0, far 1: the LLFF

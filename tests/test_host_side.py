@@ -86,7 +86,8 @@ def test_argument_validation_needs_no_gpu(hiplib):
     khu = ww // 64
     act_units = 1 + v + khu * (1 + (dd - 1) + v) + (ww // 128) * v
     grad_units = (ww // 128) * v + khu * v + (dd - 1) * khu + khu + 1
-    assert a8 == 36 * 2 * act_units * 1024 and g8 == 36 * 2 * grad_units * 1024 and m8 == 3 * 8 * (dd - 1 + 2 * v) * 2 * 1024
+    # (+ the 256-byte scale / statistics record behind the gradient units)
+    assert a8 == 36 * 2 * act_units * 1024 and g8 == 36 * 2 * grad_units * 1024 + 256 and m8 == 3 * 8 * (dd - 1 + 2 * v) * 2 * 1024
     assert a8 < 0.6 * a16 and g8 < 0.6 * g16   # (half the bytes per point; 36 records against the 32-point kernels' 32 tiles)
     # networks outside the 48-point kernels are refused (and train in plain bf16)
     d_deep = _hip.MlpDesc(**{k: getattr(d, k) for k, _ in d._fields_})

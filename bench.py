@@ -170,7 +170,7 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pos
     if dist is not None:
         parallel.broadcast_parameters(models)
     bucket = parallel.FlatGradBucket(models)
-    opt = torch.optim.Adam(bucket.params, lr=5e-4, fused=True)  # one multi-tensor kernel instead of seven
+    opt = torch.optim.Adam(bucket.params, lr=5e-4, fused=True, capturable=True)  # one multi-tensor kernel instead of seven; replayable
     from nerf import synthetic as syn
     image = torch.rand(1, H, W, 3, device=dev)
     selector = nerf.MultiViewRaySelector(H, W, [torch.from_numpy(syn.scene_pose(pose_id))], [torch.from_numpy(syn.intrinsic(H, W))], 2.0, 6.0,
@@ -179,11 +179,11 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pos
     # in the kernels, loss head + upstream gradients in one launch, backward, exchange, fused Adam (nerf.FusedTrainStep)
     fused = nerf.FusedTrainStep(models[0], models[1], selector, cfg, bucket, ex, ed, n_rays, seed=1234 + pose_id)
 
-    def step():
-        fused.forward_backward()
-        bucket.all_reduce_mean()
-        opt.step()
-    for _ in range(3):
+    # ... replayed as HIP graphs: one graph at N = 1; at N > 1 three graphs around the exchange - draw .. fine backward | coarse
+    # backward | Adam, each network's all-reduce launched eagerly in between (nerf.GraphedTrainStep)
+    graphed = nerf.GraphedTrainStep(fused, opt, eager_iterations=3, use_graphs=os.environ.get("DEXNERF_BENCH_NO_GRAPH", "") != "1")
+    step = graphed.step
+    for _ in range(6):
         step()
     torch.cuda.synchronize()
     if dist is not None:
@@ -200,7 +200,8 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pos
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     res = {"rays_per_s": world * n_rays / dt, "ms_per_step": dt * 1e3, "rays_per_step_per_gpu": n_rays, "n_gpus": world,
-           "what": "device pixel draw + ray rows + fwd + loss + bwd + fused Adam (nerf.FusedTrainStep), 64+128 samples, perturb + noise 0.2, D8/W256 x2"}
+           "hip_graphs_per_step": len(graphed.graphs) if graphed.graphs else 0, "graph_fallback": graphed.fallback_reason,
+           "what": "device pixel draw + ray rows + fwd + loss + bwd + fused Adam (nerf.FusedTrainStep under nerf.GraphedTrainStep), 64+128 samples, perturb + noise 0.2, D8/W256 x2"}
     # roofline of the step: HBM-bound by construction - the saved activations and gradients are written
     # once by the forward / backward chains and read once by the weight-gradient kernel; MFMA rate beside it (3x forward FLOP)
     nbytes = 0
@@ -227,8 +228,42 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pos
         res["allreduce_ms"] = evs[0].elapsed_time(evs[1]) / 10
         res["allreduce_bytes"] = int(bucket.flat.numel() * 4)
         res["rccl_ranks"] = world
-        res["what"] += "; data-parallel: per-network RCCL all-reduce (fine overlapped with the coarse backward) + div, every rank its own rays"
+        res["what"] += "; data-parallel: per-network RCCL all-reduce (ReduceOp.AVG; the fine one overlapped with the coarse backward's graph), every rank its own rays"
     return res
+
+
+def sharded_render_rate(dev, rank, dist, steps=3):
+    """ONE 800x800 image (BASELINE configs[3]: 64 + 192 samples, D8/W256) rendered by all ranks together - nerf.parallel.render_sharded:
+    every rank renders its block of rows, one all_gather per output map hands every rank the whole image.  Strong scaling of a
+    single image, next to the weak-scaling headline (one image per rank).  all_gather_ms: the same exchange alone."""
+    import nerf
+    from nerf import parallel
+    h = w = 800
+    models, cfg, ro, rd, ex, ed = build_scene(dev, 0, h, w, 64, 192)      # (every rank: the SAME view)
+    world = dist.get_world_size()
+
+    def block(ro_b, rd_b):
+        cfg.nerf.validation.chunksize = ro_b.shape[0] * ro_b.shape[1]
+        return tuple(render(models, cfg, ro_b, rd_b, ex, ed))
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        torch.cuda.synchronize(); dist.barrier()
+        t = torch.tensor([(time.perf_counter() - t0) / steps], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), out
+    dt, out = timed(lambda: parallel.render_sharded(block, ro, rd))
+    lo, hi = parallel.shard_bounds(h, rank, world)
+    mine = block(ro[lo:hi], rd[lo:hi])
+    dt_gather, _ = timed(lambda: parallel.render_sharded(lambda a, b: mine, ro, rd))
+    assert all(o is None or o.shape[0] == h for o in out)
+    return {"workload": "ONE 800x800 image, 64+192 samples, D8/W256, rows split over the ranks (parallel.render_sharded)",
+            "render_sharded_ms": dt * 1e3, "all_gather_ms": dt_gather * 1e3, "rays_per_s": h * w / dt, "n_gpus": world,
+            "gathered_bytes_per_rank": int(sum(o.numel() * o.element_size() for o in out if o is not None))}
 
 
 def dex_agreement(out, ref, sel, dev):
@@ -336,6 +371,8 @@ def main():
         # the data-parallel training step (BASELINE configs 4 / 5 are training configs): collective inside, so every rank runs it
         train_dp = train_rate(models, cfg, ro, rd, ex, ed, dist=dist, pose_id=7 + rank)
         note(f"data-parallel training step: {train_dp['ms_per_step']:.2f} ms, all-reduce alone {train_dp['allreduce_ms']:.3f} ms")
+        train_dp["render_sharded"] = sharded_render_rate(dev, rank, dist)
+        note(f"one 800x800 image over {world} ranks: {train_dp['render_sharded']['render_sharded_ms']:.1f} ms, gather alone {train_dp['render_sharded']['all_gather_ms']:.2f} ms")
     result = None
     if rank == 0:
         rdt = render_dtype()   # 'bf16' runs its no-grad renders in fp16 under the default render policy (nerf.set_render_policy)

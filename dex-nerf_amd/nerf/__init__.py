@@ -9,7 +9,7 @@ host-side numpy + PIL (nerf/datasets.py, nerf/llff.py).
 from . import models, parallel, synthetic  # noqa: F401  (scripts use getattr(models, cfg.models.coarse.type))
 from ._ops import get_precision, get_render_policy, s8_grad_stats, set_precision, set_render_policy, set_s8_grad_scale  # noqa: F401
 from .cfgnode import CfgNode  # noqa: F401
-from .fused_step import FusedTrainStep  # noqa: F401
+from .fused_step import FusedTrainStep, GraphedTrainStep  # noqa: F401
 from .models import *  # noqa: F401,F403
 from .nerf_helpers import *  # noqa: F401,F403
 from .train_utils import *  # noqa: F401,F403

@@ -46,8 +46,21 @@ class FusedTrainStep:
                 and train_fused_ok(model_coarse) and train_fused_ok(model_fine) and model_coarse.use_viewdirs and model_fine.use_viewdirs)
 
     def forward_backward(self):
-        """One iteration up to (and excluding) the gradient exchange and the optimizer step.  Returns the device tensor
-        [loss, mse_coarse, mse_fine]; the parameter gradients are in the bucket."""
+        """One iteration up to (and excluding) the end of the gradient exchange and the optimizer step.  Returns the device tensor
+        [loss, mse_coarse, mse_fine]; the parameter gradients are in the bucket (world > 1: each network's all-reduce is started the
+        moment its backward is enqueued - FlatGradBucket.segment_ready - and finished by bucket.all_reduce_mean())."""
+        mc, mf = self.models
+        mc._grad_sink.forward_issued(); mf._grad_sink.forward_issued()
+        self.bucket.zero()
+        self.forward_and_fine_backward(_zero=False)
+        mf._grad_sink.backward_done()     # (world > 1: the fine network's all-reduce starts here, under the coarse half)
+        self.coarse_backward()
+        mc._grad_sink.backward_done()
+        return self.loss3
+
+    # The two halves a data-parallel loop replays as separate HIP graphs around the fine network's exchange (GraphedTrainStep): only
+    # this library's launches and one memset - no bucket bookkeeping, no collective.
+    def forward_and_fine_backward(self, _zero=True):
         mc, mf = self.models
         sel = self.selector
         rays, target = _ops.select_rays_draw(sel.height, sel.width, sel.cams, sel.view, sel.near, sel.far, self.rng_state, self.num_rays,
@@ -56,16 +69,102 @@ class FusedTrainStep:
         maps, saved = _ops.render_rays_train(pc, pf, rays, self.nc, self.nf, self.lindisp, self.noise_std, self.white, [], None, prec=prec,
                                              rng_state=self.rng_state, perturb=self.perturb)
         self.loss3, g_c, g_f = _ops.mse2_loss(maps[0], maps[3], target, self.luminance, self.rng_state)
-        sink_c, sink_f = mc._grad_sink, mf._grad_sink
-        sink_c.forward_issued(); sink_f.forward_issued()
-        self.bucket.zero()
-        views_c, views_f = sink_c.views(mc), sink_f.views(mf)
+        if _zero:
+            self.bucket.flat.zero_()
+        views_c, views_f = mc._grad_sink.views(mc), mf._grad_sink.views(mf)
         if views_c is None or views_f is None:
             raise RuntimeError("FusedTrainStep: a parameter's .grad is no longer the FlatGradBucket's view")
         none3 = (None, None, None)
         keep = [_ops.render_rays_backward(pc, pf, saved, none3, (g_f, None, None), views_c, views_f, nets=2)]
-        sink_f.backward_done()     # (world > 1: the fine network's all-reduce starts here, under the coarse half)
-        keep.append(_ops.render_rays_backward(pc, pf, saved, (g_c, None, None), none3, views_c, views_f, nets=1))
-        sink_c.backward_done()
+        self._half = (pc, pf, saved, g_c, views_c, views_f)
         self._keep = (keep, saved, maps, rays, target, g_c, g_f)   # alive until the next call (stream-ordered allocator)
-        return self.loss3
+
+    def coarse_backward(self):
+        pc, pf, saved, g_c, views_c, views_f = self._half
+        none3 = (None, None, None)
+        self._keep[0].append(_ops.render_rays_backward(pc, pf, saved, (g_c, None, None), none3, views_c, views_f, nets=1))
+
+
+class GraphedTrainStep:
+    """A FusedTrainStep + the gradient exchange + the optimizer step, replayed as HIP graphs (reference loop:
+    train_dexnerf_rgb.py:229-289 - one optimizer step per drawn batch).
+
+    world == 1: ONE graph (draw .. Adam).  world > 1: the collective stays outside the graphs -
+
+        graph A  pixel draw, ray rows, coarse + fine render, loss head, fine network's backward
+        all-reduce of the fine segment, asynchronous on torch.distributed's stream ..........  overlapped with
+        graph B  coarse network's backward
+        all-reduce of the coarse segment; both waited for on the compute stream
+        graph C  optimizer step (fused Adam over the flat parameter list)
+
+    RCCL averages inside the collective (ReduceOp.AVG); gloo (CPU tests, one-GPU rehearsals) sums and one division follows.
+    The first `eager_iterations` calls run eagerly (they initialise the optimizer moments and the packed weight streams); the next
+    one captures and replays.  If capture fails the loop goes on eagerly and `fallback_reason` says why."""
+
+    def __init__(self, fused, optimizer, eager_iterations=3, use_graphs=True):
+        self.fused, self.opt, self.bucket = fused, optimizer, fused.bucket
+        self.eager_left = int(eager_iterations)
+        self.use_graphs = bool(use_graphs)
+        self.graphs = None
+        self.fallback_reason = None
+
+    def _eager(self):
+        self.fused.forward_backward()
+        self.bucket.all_reduce_mean()
+        self.opt.step()
+
+    def _capture(self):
+        from .parallel import world_info
+        world = world_info()[1]
+        torch.cuda.synchronize()
+        if world == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.fused.forward_and_fine_backward()
+                self.fused.coarse_backward()
+                self.opt.step()
+            return [g]
+        ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self.fused.forward_and_fine_backward()
+        with torch.cuda.graph(gb, pool=ga.pool()):     # (reads what graph A allocated: one memory pool, replayed in capture order)
+            self.fused.coarse_backward()
+        with torch.cuda.graph(gc, pool=ga.pool()):
+            self.opt.step()
+        return [ga, gb, gc]
+
+    def _replay(self):
+        import torch.distributed as dist
+        from .models import mark_parameters_updated
+        from .parallel import _avg_in_collective, world_info
+        if len(self.graphs) == 1:
+            self.graphs[0].replay()
+        else:
+            ga, gb, gc = self.graphs
+            avg = _avg_in_collective()
+            op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+            ga.replay()
+            w_fine = dist.all_reduce(self.bucket.segment(1), op=op, async_op=True)
+            gb.replay()
+            w_coarse = dist.all_reduce(self.bucket.segment(0), op=op, async_op=True)
+            w_fine.wait(); w_coarse.wait()
+            if not avg:
+                self.bucket.flat.div_(world_info()[1])
+            gc.replay()
+        mark_parameters_updated()      # the replayed optimizer step ran no Python hook
+
+    def step(self):
+        """One training iteration.  The loss of the iteration is in self.fused.loss3 (device)."""
+        if self.graphs is not None:
+            return self._replay()
+        if self.eager_left > 0 or not self.use_graphs:
+            self.eager_left -= 1
+            return self._eager()
+        try:
+            self.graphs = self._capture()          # a capture only records ...
+        except Exception as exc:  # noqa: BLE001
+            self.graphs, self.use_graphs = None, False
+            self.fallback_reason = f"{type(exc).__name__}: {exc}"
+            torch.cuda.synchronize()
+            return self._eager()
+        return self._replay()                      # ... this iteration's step runs here

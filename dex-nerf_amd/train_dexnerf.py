@@ -210,7 +210,7 @@ def main(argv=None):
     parallel.broadcast_parameters(student)
     torch.manual_seed(args.seed + 1000 + rank)
     bucket = parallel.FlatGradBucket(student)
-    use_graph = (world == 1) and not args.no_hip_graph
+    use_graph = not args.no_hip_graph         # (world > 1: graphs around the exchange, nerf.GraphedTrainStep; the autograd step only with one rank)
     lr_t = torch.tensor(args.lr, dtype=torch.float32, device=dev)   # a device scalar: the schedule is applied by fill_()
     opt = torch.optim.Adam(bucket.params, lr=lr_t, fused=True, capturable=True)
     start = 0
@@ -237,14 +237,12 @@ def main(argv=None):
     if not args.autograd_step and nerf.FusedTrainStep.applicable(student[0], student[1], cfg, ex, ed, args.num_random_rays) and not args.ndc:
         fused = nerf.FusedTrainStep(student[0], student[1], selector, cfg, bucket, ex, ed, args.num_random_rays, seed=args.seed + 7919 * rank,
                                     luminance=args.ir, first_iteration=start)
+    graphed = nerf.GraphedTrainStep(fused, opt, eager_iterations=3, use_graphs=use_graph) if fused is not None else None
+    use_graph = use_graph and world == 1      # (the autograd step's single graph below: one rank only)
 
     def iteration():
-        """select rays -> coarse + fine render -> loss -> backward -> (all-reduce) -> Adam; device-side state only."""
-        if fused is not None:
-            fused.forward_backward()     # (the loss stays in fused.loss3: read where it is logged)
-            bucket.all_reduce_mean()
-            opt.step()
-            return
+        """The torch composition (--autograd-step, NDC rays, configurations outside nerf.FusedTrainStep): select rays -> coarse +
+        fine render -> loss -> backward -> (all-reduce) -> Adam; device-side state only."""
         rays, target = selector.select(selector.random_pixels(args.num_random_rays))
         if args.ndc:
             # run_one_iter_of_nerf's NDC branch (reference train_utils.py:240-262) on the selected rows: origins / directions
@@ -266,15 +264,24 @@ def main(argv=None):
         opt.step()
         loss_t.copy_(loss.detach())
 
-    graph = None
+    graph, graph_warned = None, False
     history = []
     t0 = time.perf_counter()
+    t_steady = None
     loss_val = psnr = float("nan")
     for it in range(start, args.iters):
         selector.view.fill_(int(np.random.randint(len(train_ids))))                 # one random training view per iteration
         lr = args.lr * args.lr_decay_factor ** (it / (args.lr_decay * 1000))         # train_dexnerf_rgb.py:284-289
         lr_t.fill_(lr)
-        if use_graph and graph is None and it >= start + 3:
+        if it == start + 20:                   # past the eager iterations and the capture: the steady part is timed from here
+            torch.cuda.synchronize()
+            t_steady = time.perf_counter()
+        if graphed is not None:
+            graphed.step()
+            if graphed.fallback_reason and rank == 0 and not args.quiet and not graph_warned:
+                graph_warned = True
+                print(f"[train] HIP-graph capture unavailable ({graphed.fallback_reason}); launching eagerly", flush=True)
+        elif use_graph and graph is None and it >= start + 3:
             # three eager iterations have initialised every lazy state (optimizer moments, packed streams); capture the
             # fourth and replay it from here on.  Anything that cannot be captured falls back to eager launches.
             try:
@@ -325,6 +332,9 @@ def main(argv=None):
     elapsed = time.perf_counter() - t0
     result = dict(history=history, final_loss=loss_val, final_psnr=psnr, seconds=elapsed,
                   rays_per_s=world * args.num_random_rays * (args.iters - start) / max(elapsed, 1e-9))
+    if t_steady is not None and args.iters - start > 20:
+        result["steady_ms_per_iter"] = (t0 + elapsed - t_steady) * 1e3 / (args.iters - start - 20)
+    result["hip_graphs"] = len(graphed.graphs) if (graphed is not None and graphed.graphs) else int(graph is not None)   # graphs replayed per iteration
     if args.precision == "bf16-s8":
         result["s8_saturated_max"] = s8_saturated_max
     if args.save and rank != 0 and os.environ.get("DEXNERF_SAVE_ALL_RANKS"):   # rehearsals: compare the replicas

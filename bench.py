@@ -170,7 +170,8 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pos
     if dist is not None:
         parallel.broadcast_parameters(models)
     bucket = parallel.FlatGradBucket(models)
-    opt = torch.optim.Adam(bucket.params, lr=5e-4, fused=True, capturable=True)  # one multi-tensor kernel instead of seven; replayable
+    # Adam over the flat parameter buffer: one launch, clears the gradients in the same pass (nerf.FlatAdam; what train_dexnerf.py steps)
+    opt = nerf.FlatAdam(bucket, lr=5e-4, zero_grads=True)
     from nerf import synthetic as syn
     image = torch.rand(1, H, W, 3, device=dev)
     selector = nerf.MultiViewRaySelector(H, W, [torch.from_numpy(syn.scene_pose(pose_id))], [torch.from_numpy(syn.intrinsic(H, W))], 2.0, 6.0,
@@ -201,7 +202,7 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pos
         dt = float(t.item())
     res = {"rays_per_s": world * n_rays / dt, "ms_per_step": dt * 1e3, "rays_per_step_per_gpu": n_rays, "n_gpus": world,
            "hip_graphs_per_step": len(graphed.graphs) if graphed.graphs else 0, "graph_fallback": graphed.fallback_reason,
-           "what": "device pixel draw + ray rows + fwd + loss + bwd + fused Adam (nerf.FusedTrainStep under nerf.GraphedTrainStep), 64+128 samples, perturb + noise 0.2, D8/W256 x2"}
+           "what": "device pixel draw + ray rows + fwd + loss + bwd + Adam (nerf.FusedTrainStep + nerf.FlatAdam under nerf.GraphedTrainStep), 64+128 samples, perturb + noise 0.2, D8/W256 x2"}
     # roofline of the step: HBM-bound by construction - the saved activations and gradients are written
     # once by the forward / backward chains and read once by the weight-gradient kernel; MFMA rate beside it (3x forward FLOP)
     nbytes = 0

@@ -15,7 +15,7 @@
 
 namespace dn {
 
-enum : uint32_t { kRngStreamJitter = 0, kRngStreamNoiseCoarse = 1, kRngStreamU = 2, kRngStreamNoiseFine = 3, kRngStreamPixels = 4 };
+enum : uint32_t { kRngStreamJitter = 0, kRngStreamNoiseCoarse = 1, kRngStreamU = 2, kRngStreamNoiseFine = 3, kRngStreamPixels = 4, kRngStreamView = 5 };
 
 struct RngRef {
   const uint32_t* state;   // device record {seed_lo, seed_hi, cur, nxt}, or NULL: no in-kernel draws

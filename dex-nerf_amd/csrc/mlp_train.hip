@@ -660,7 +660,7 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
 
   // wave -> (n-tile, subset of k-tiles)
   const int ntile = wave % S::NTN;
-  const int kgroup = wave / S::NTN;
+  const int kgroup = S::KGROUPS == 1 ? 0 : wave / S::NTN;   // (a constant where every wave has its own n-tile: the epilogue then knows which k-tiles a wave holds)
 
   // transposing read: lane (16-lane group g, li) supplies row (li>>2) / column chunk (li&3) of a 4 x 16 block and
   // receives feature column li; group g covers feature sub-block fs = g&1 and k-half hh = g>>1 of the MFMA operand
@@ -1046,55 +1046,131 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
       if (lane == 0 && tot != 0u) atomicAdd(p.stats_block + kS8BlockSaturated + k, tot);
     }
   }
+  if constexpr (S::S8) {   // (in place: the epilogue below only moves values)
+#pragma unroll
+    for (int k = 0; k < S::J; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[k][r] *= out_scale;
+  }
   // ---- add this workgroup's partial: D[i][j] sits in lane (j = lane&31, half = lane>>5), register r, i = acc_row(r, half)
   const int jl = lane & 31, half = lane >> 5;
-  static_for<S::J>([&](auto j_c) {
-    constexpr int j = decltype(j_c)::value;
-    const int kt = kgroup + j * S::KGROUPS;
-    if (kt < S::KT) {
-      // fragment row / column i (0..31) = (piece s of the tile's two, lane half h, element e): i = 16 h + 8 s + e (see lane_off)
-      auto piece_of = [](int i) { return (i >> 3) & 1; };
-      auto half_of = [](int i) { return i >> 4; };
-      auto feature_of = [&](int i) { return acc_row(piece_of(i) * 8 + (i & 7), half_of(i)); };
-      // 8-bit layout: fragment `frag` of a hidden vector, index i = 16 fs + li -> lane group 2 (frag % 2) + fs, piece
-      // 2 (frag / 2) + li / 8, element li % 8 (g48_hidden_col); relative to the vector's first feature
-      auto feature48 = [&](int frag, int i) { return g48_hidden_col(2 * (frag >> 1) + piece_of(i), 2 * (frag & 1) + half_of(i), i & 7); };
-      int col;
-      if (kt < S::XT) col = S::S8 ? feature48(kt, jl) : 32 * kt + feature_of(jl);
-      else if (kt < S::KT - 1) {
-        int pc;
-        if constexpr (S::S8) {
-          // xyz panel (two fragments): lane group 2 (fragment) + fs, slot = byte li; view-direction panel (one fragment): lanes of
-          // groups 0 / 1 hold [their 8 slots | those of groups 2 / 3]
-          const int li_c = jl & 15, fs_c = jl >> 4;
-          pc = p.pe_kind == 1 ? g48_pe_col(1, 2 * (kt - S::XT) + fs_c, li_c, p.pe_L) : g48_pe_col(2, fs_c + 2 * (li_c >> 3), li_c & 7, p.pe_L);
-        } else {
-          const int pe_piece = 2 * (kt - S::XT) + piece_of(jl);
-          pc = pe_slot_col(p.pe_L, half_of(jl), pe_piece * 8 + (jl & 7));
-        }
-        col = pc >= 0 ? p.col_pe0 + pc : -1;
-      } else col = (jl == 0) ? -2 : -1;  // all-ones tile: column 0 carries the bias gradient
+  // fragment row / column i (0..31) = (piece s of the tile's two, lane half h, element e): i = 16 h + 8 s + e (see lane_off)
+  auto piece_of = [](int i) { return (i >> 3) & 1; };
+  auto half_of = [](int i) { return i >> 4; };
+  auto feature_of = [&](int i) { return acc_row(piece_of(i) * 8 + (i & 7), half_of(i)); };
+  // 8-bit layout: fragment `frag` of a hidden vector, index i = 16 fs + li -> lane group 2 (frag % 2) + fs, piece
+  // 2 (frag / 2) + li / 8, element li % 8 (g48_hidden_col); relative to the vector's first feature
+  auto feature48 = [&](int frag, int i) { return g48_hidden_col(2 * (frag >> 1) + piece_of(i), 2 * (frag & 1) + half_of(i), i & 7); };
+  // dW goes to memory through LDS: in the accumulator layout a lane's 16 values are 16 rows and its neighbours hold 4-float runs
+  // scattered over a 64-column span - as atomics that is a 16-byte request each, and the reduction over the workgroups of a layer
+  // was a third of the as-shipped nets' launch (scripts/micro/reduce_probe.hip: 12x between scattered and 256-byte-contiguous
+  // float atomics).  A round = the k-tiles that make up to 64 consecutive dW columns - hidden inputs: k-tiles 2r and 2r + 1; the
+  // encoding panel: its one or two k-tiles, laid down by dW column.  The waves holding those k-tiles write their 32 x 32 blocks
+  // into a [rows][64] image (the tile buffers are free by now), then every wave adds whole rows: one instruction = consecutive
+  // floats of one dW row.
+  constexpr int IMG_LD = 64 + 4;   // floats per image row (+4: rows 32 banks apart would serialise the column writes)
+  constexpr int IMG_ROWS = S::CUSTOM ? 8 : 32 * S::NTN;   // (custom dY: fc_rgb / fc_alpha / fc_out, at most 4 rows)
+  static_assert(IMG_ROWS * IMG_LD * 4 <= S::STAGES * BUF, "weight_grad: the reduction image fits the tile buffers");
+  float* img = reinterpret_cast<float*>(smem);
+  const int n_rows = S::CUSTOM ? p.custom_rows : 32 * S::NTN;
+  // image row of accumulator register r (custom dY: rows beyond custom_rows - the other piece of the pair, padding - get -1)
+  auto row_of = [&](int r) {
+    const int irow = acc_row(r, half);
+    if constexpr (S::CUSTOM) {
+      // custom piece: row = 8 (lane half / lane group) + e (bf16: piece 0 of the pair read; 8-bit: piece dy_odd of the unit - the
+      // other one was zeroed)
+      const bool mine = piece_of(irow) == (S::S8 ? p.dy_odd : 0);
+      const int n = half_of(irow) * 8 + (irow & 7);
+      return (mine && n < p.custom_rows) ? n : -1;
+    } else {
+      return S::S8 ? feature48(ntile, irow) : 32 * ntile + feature_of(irow);
+    }
+  };
+  // lay the block of k-tile KT_ (held in acc[KT_ / KGROUPS] by the waves of k-group KT_ % KGROUPS) into the image at column `col`
+  auto lay = [&](auto kt_c, int col) {
+    constexpr int kt = decltype(kt_c)::value;
+    constexpr int j = kt / S::KGROUPS;
+    if (kgroup != kt % S::KGROUPS || col < 0) return;
+    if constexpr (S::CUSTOM) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int irow = acc_row(r, half);
-        int n = S::S8 ? feature48(ntile, irow) : 32 * ntile + feature_of(irow);
-        if constexpr (S::CUSTOM) {
-          // custom piece: row = 8 (lane half / lane group) + e (bf16: piece 0 of the pair read; 8-bit: piece dy_odd of the unit - the
-          // other one was zeroed)
-          const bool mine = piece_of(irow) == (S::S8 ? p.dy_odd : 0);
-          n = mine ? half_of(irow) * 8 + (irow & 7) : p.custom_rows;
-          if (n >= p.custom_rows) continue;
-        }
+        const int n = row_of(r);
+        if (n >= 0) img[n * IMG_LD + col] = acc[j][r];
+      }
+    } else {
+      // row of register r = row of register 0 + a compile-time distance (both layouts place r's bits apart from the lane half's
+      // and the n-tile's): one address register, immediate offsets
+      float* at = img + row_of(0) * IMG_LD + col;
+      static_for<16>([&](auto r_c) {
+        constexpr int r = decltype(r_c)::value;
+        constexpr int i = acc_row(r, 0);
+        constexpr int dn = S::S8 ? g48_hidden_col((i >> 3) & 1, i >> 4, i & 7) - g48_hidden_col(0, 0, 0)
+                                 : acc_row(((i >> 3) & 1) * 8 + (i & 7), i >> 4) - acc_row(0, 0);
+        at[dn * IMG_LD] = acc[j][r];
+      });
+    }
+  };
+  // add the image's first n_cols columns to dW[:, col0 ...]: wave w takes rows w, w + 8, ...
+  // (the workgroups of a layer finish together and would walk the rows in step - every one queueing on the same cache line while
+  // the memory-side atomic units of the others idle: workgroup `wg` starts wg row-groups further on)
+  constexpr int ROW_GROUPS = (IMG_ROWS + 7) / 8;
+  const int q0 = wg % ROW_GROUPS;
+  auto add_rows = [&](int col0, int n_cols) {
+#pragma unroll
+    for (int q = 0; q < ROW_GROUPS; ++q) {
+      const int qq = (q + q0 >= ROW_GROUPS) ? q + q0 - ROW_GROUPS : q + q0;
+      const int n = wave + 8 * qq;
+      if (n < n_rows && lane < n_cols) {
 #if DN_WG_EPI == 1
-        if (col >= 0 && acc[j][r] == 1.2345f) p.dW[static_cast<long long>(n) * p.ldw + col] = 1.0f;
+        if (img[n * IMG_LD + lane] == 1.2345f) p.dW[static_cast<long long>(n) * p.ldw + col0 + lane] = 1.0f;
 #else
-        const float val = S::S8 ? acc[j][r] * out_scale : acc[j][r];
-        if (col >= 0) atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col, val);
-        else if (col == -2 && p.db != nullptr) atomicAdd(p.db + n, val);
+        atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col0 + lane, img[n * IMG_LD + lane]);
 #endif
       }
     }
+  };
+  static_for<S::XT / 2>([&](auto r_c) {
+    constexpr int rr = decltype(r_c)::value;
+    __syncthreads();   // the tile buffers / the previous round's image are done with
+    static_for<2>([&](auto par_c) {
+      constexpr int kt = 2 * rr + decltype(par_c)::value;
+      lay(std::integral_constant<int, kt>{}, (S::S8 ? feature48(kt, jl) : 32 * kt + feature_of(jl)) - 64 * rr);
+    });
+    __syncthreads();
+    add_rows(64 * rr, 64);
   });
+  if constexpr (S::PET > 0) {
+    __syncthreads();
+    static_for<S::PET>([&](auto t_c) {
+      constexpr int kt = S::XT + decltype(t_c)::value;
+      int pc;   // dW column (relative to the panel's first) of this lane's slot, -1: padding
+      if constexpr (S::S8) {
+        // xyz panel (two fragments): lane group 2 (fragment) + fs, slot = byte li; view-direction panel (one fragment): lanes of
+        // groups 0 / 1 hold [their 8 slots | those of groups 2 / 3]
+        const int li_c = jl & 15, fs_c = jl >> 4;
+        pc = p.pe_kind == 1 ? g48_pe_col(1, 2 * (kt - S::XT) + fs_c, li_c, p.pe_L) : g48_pe_col(2, fs_c + 2 * (li_c >> 3), li_c & 7, p.pe_L);
+      } else {
+        const int pe_piece = 2 * (kt - S::XT) + piece_of(jl);
+        pc = pe_slot_col(p.pe_L, half_of(jl), pe_piece * 8 + (jl & 7));
+      }
+      lay(std::integral_constant<int, kt>{}, pc);
+    });
+    __syncthreads();
+    add_rows(p.col_pe0, 3 + 6 * p.pe_L);
+  }
+  // the all-ones k-tile: its column 0 is the bias gradient - one value per row, added 64 rows per instruction (from the registers
+  // it was two lanes per instruction, every workgroup of the layer on the same four cache lines: same-line atomics serialise)
+  if (p.db != nullptr) {
+    __syncthreads();
+    lay(std::integral_constant<int, S::KT - 1>{}, jl == 0 ? 0 : -1);
+    __syncthreads();
+    const int n = 64 * wave + lane;
+    if (n < n_rows) {
+#if DN_WG_EPI != 1
+      atomicAdd(p.db + n, img[n * IMG_LD]);
+#endif
+    }
+  }
 }
 
 // ---- exact-fp32 variant (the parity mode) ---------------------------------------------------------------------
@@ -1130,7 +1206,7 @@ __device__ __forceinline__ void weight_grad_unit_f32(const WgParams& p, int wg, 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ntile = wave % S::NTN;
-  const int kgroup = wave / S::NTN;
+  const int kgroup = S::KGROUPS == 1 ? 0 : wave / S::NTN;   // (a constant where every wave has its own n-tile: the epilogue then knows which k-tiles a wave holds)
   const int i = lane & 31, kk = lane >> 5;                       // operand row / column and point parity of this lane
   // byte offset of feature i's element inside a tile's 4-piece group, for point parity kk (point 2m+kk adds 32*m bytes)
   const int feat_off = (i >> 3) * kWg32PieceStride + (((i & 7) >> 2) * 32 + kk) * 16 + (i & 3) * 4;
@@ -1498,6 +1574,9 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
   // divide the workgroups (one per CU) among the units in proportion to the pieces each streams - the 8-bit kernel: to the cycles a
   // tile costs, WgShape::COST - (largest remainder)
   const long long tiles = (n_points + 31) / 32;
+  // (one workgroup per CU.  Two per CU on half the LDS - an instance of the W = 128 layer shapes only, 128 VGPRs - was tried for the
+  // as-shipped nets, whose launches are bound by the wait / barrier / LDS round trip of a tile: the tile loop got 13-26 us shorter,
+  // the reduction of twice as many partials 50 us longer - DESIGN.md section 4.6)
   int total_wg = device_cus();
   if (total_wg < n_units) total_wg = n_units;
   long long cost[kWgMaxUnits], cost_sum = 0;

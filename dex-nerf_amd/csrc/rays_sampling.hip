@@ -92,7 +92,7 @@ __global__ void select_rays_kernel(RayBundleArgs a, float near, float far, const
 // pix == NULL: the pixels are DRAWN here - element i of this iteration's draw without replacement, a keyed permutation of the
 // H W pixels (dn_rng.h feistel_permute; reference train_dexnerf_rgb.py:229-236: np.random.choice(H W, n, replace=False)) - from
 // the RNG state's NEXT iteration counter, which thread 0 then publishes as the CURRENT one for the rest of the iteration.
-__global__ void select_rays_indirect_kernel(const float* __restrict__ cams, const int* __restrict__ view, int height, int width,
+__global__ void select_rays_indirect_kernel(const float* __restrict__ cams, const int* __restrict__ view, int n_views, int height, int width,
                                             float near, float far, const int64_t* __restrict__ pix, int64_t n,
                                             const float* __restrict__ images, int channels, float* __restrict__ rays,
                                             float* __restrict__ target, uint32_t* __restrict__ rng_state, int64_t* __restrict__ pix_out) {
@@ -103,7 +103,13 @@ __global__ void select_rays_indirect_kernel(const float* __restrict__ cams, cons
     if (i == 0) rng_state[2] = iteration;   // (nobody in this launch reads word 2)
   }
   if (i >= n) return;
-  const int v = *view;
+  int v;
+  if (view != nullptr) v = *view;
+  else {   // the iteration's training view drawn here too (reference: img_idx = np.random.choice(i_train), train_dexnerf_rgb.py:223)
+    uint32_t w[4];
+    rng_words(rng_state[0], rng_state[1], iteration, kRngStreamView, 0, w);
+    v = static_cast<int>(w[0] % static_cast<uint32_t>(n_views));
+  }
   const float* cam = cams + static_cast<int64_t>(v) * 16;
   const float fx = cam[12], cx = cam[13], cy = cam[14];
   int64_t px;
@@ -484,21 +490,21 @@ extern "C" int dn_select_rays_indirect(int height, int width, const float* cams,
   DN_REQUIRE(target == nullptr || (images != nullptr && channels >= 3), "dn_select_rays_indirect: target requested without images of >= 3 channels");
   const int block = 256;
   const unsigned grid = static_cast<unsigned>((n_rays + block - 1) / block);
-  hipLaunchKernelGGL(select_rays_indirect_kernel, dim3(grid), dim3(block), 0, as_stream(stream), cams, view, height, width, near,
+  hipLaunchKernelGGL(select_rays_indirect_kernel, dim3(grid), dim3(block), 0, as_stream(stream), cams, view, 0, height, width, near,
                      far, pixel_index, n_rays, images, channels, rays, target, static_cast<uint32_t*>(nullptr), static_cast<int64_t*>(nullptr));
   return check_launch("dn_select_rays_indirect");
 }
 
-extern "C" int dn_select_rays_draw(int height, int width, const float* cams, const int32_t* view, float near, float far,
+extern "C" int dn_select_rays_draw(int height, int width, const float* cams, const int32_t* view, int n_views, float near, float far,
                                    uint32_t* rng_state, int64_t n_rays, const float* images, int channels, float* rays, float* target,
                                    int64_t* pixel_index_out, dn_stream_t stream) {
-  DN_REQUIRE(height > 0 && width > 0 && cams && view && rng_state && rays && n_rays >= 1, "dn_select_rays_draw: bad arguments");
+  DN_REQUIRE(height > 0 && width > 0 && cams && (view || n_views >= 1) && rng_state && rays && n_rays >= 1, "dn_select_rays_draw: bad arguments");
   DN_REQUIRE(n_rays <= static_cast<int64_t>(height) * width, "dn_select_rays_draw: more rays than pixels (the draw is without replacement)");
   DN_REQUIRE(static_cast<int64_t>(height) * width < (1LL << 31), "dn_select_rays_draw: image too large");
   DN_REQUIRE(target == nullptr || (images != nullptr && channels >= 3), "dn_select_rays_draw: target requested without images of >= 3 channels");
   const int block = 256;
   const unsigned grid = static_cast<unsigned>((n_rays + block - 1) / block);
-  hipLaunchKernelGGL(select_rays_indirect_kernel, dim3(grid), dim3(block), 0, as_stream(stream), cams, view, height, width, near,
+  hipLaunchKernelGGL(select_rays_indirect_kernel, dim3(grid), dim3(block), 0, as_stream(stream), cams, view, n_views, height, width, near,
                      far, static_cast<const int64_t*>(nullptr), n_rays, images, channels, rays, target, rng_state, pixel_index_out);
   return check_launch("dn_select_rays_draw");
 }

@@ -10,6 +10,7 @@ from . import models, parallel, synthetic  # noqa: F401  (scripts use getattr(mo
 from ._ops import get_precision, get_render_policy, s8_grad_stats, set_precision, set_render_policy, set_s8_grad_scale  # noqa: F401
 from .cfgnode import CfgNode  # noqa: F401
 from .fused_step import FusedTrainStep, GraphedTrainStep  # noqa: F401
+from .parallel import FlatAdam  # noqa: F401
 from .models import *  # noqa: F401,F403
 from .nerf_helpers import *  # noqa: F401,F403
 from .train_utils import *  # noqa: F401,F403

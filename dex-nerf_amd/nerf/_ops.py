@@ -89,6 +89,14 @@ def set_s8_grad_scale(scale):
     check(lib().dn_set_s8_grad_scale(float(scale)), "dn_set_s8_grad_scale")
 
 
+def adam_step(params, grads, exp_avg, exp_avg_sq, state, lr, lr_decay_per_step, betas, eps, zero_grads):
+    """dn_adam_step on flat fp32 buffers (nerf.parallel.FlatAdam).  lr: float or device scalar."""
+    lr_t = lr if torch.is_tensor(lr) else None
+    check(lib().dn_adam_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), params.numel(), ptr(state), ptr(lr_t),
+                             0.0 if lr_t is not None else float(lr), float(lr_decay_per_step), float(betas[0]), float(betas[1]),
+                             float(eps), int(bool(zero_grads)), stream()), "dn_adam_step")
+
+
 S8_RECORD_BYTES = 256     # kS8BlockBytes, csrc/mlp_geo48.h: the record behind the 8-bit saved gradients of a launch
 _s8_records = []          # device views of the records of the latest backward launches (bounded; read by s8_grad_stats)
 
@@ -176,8 +184,9 @@ def rng_fill(rng_state, stream_id, shape, normal=False):
 
 
 def select_rays_draw(height, width, cams, view, near, far, rng_state, n_rays, images=None, want_pixels=False):
-    """select_rays_indirect with the pixels drawn on the device, without replacement, from `rng_state`'s next iteration."""
-    assert view.dtype == torch.int32 and cams.dtype == torch.float32 and cams.is_contiguous() and rng_state.dtype == torch.int32
+    """select_rays_indirect with the pixels drawn on the device, without replacement, from `rng_state`'s next iteration.
+    view=None: the training view is drawn in the kernel too (uniformly from the cameras in `cams`)."""
+    assert (view is None or view.dtype == torch.int32) and cams.dtype == torch.float32 and cams.is_contiguous() and rng_state.dtype == torch.int32
     dev = cams.device
     rays = torch.empty((n_rays, 11), dtype=torch.float32, device=dev)
     target, img, channels = None, None, 0
@@ -186,7 +195,7 @@ def select_rays_draw(height, width, cams, view, near, far, rng_state, n_rays, im
         channels = img.shape[-1]
         target = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
     pix = torch.empty((n_rays,), dtype=torch.int64, device=dev) if want_pixels else None
-    check(lib().dn_select_rays_draw(height, width, ptr(cams), ptr(view), float(near), float(far), ptr(rng_state), n_rays, ptr(img), channels,
+    check(lib().dn_select_rays_draw(height, width, ptr(cams), ptr(view), int(cams.shape[0]), float(near), float(far), ptr(rng_state), n_rays, ptr(img), channels,
                                     ptr(rays), ptr(target), ptr(pix), stream()), "dn_select_rays_draw")
     return (rays, target, pix) if want_pixels else (rays, target)
 

@@ -20,7 +20,7 @@ from .train_utils import _fusable
 
 class FusedTrainStep:
     def __init__(self, model_coarse, model_fine, selector, options, bucket, encode_position_fn, encode_direction_fn, num_rays, seed=0,
-                 luminance=False, first_iteration=0):
+                 luminance=False, first_iteration=0, draw_view=False):
         opt = options.nerf.train
         self.models = (model_coarse, model_fine)
         self.selector, self.bucket = selector, bucket
@@ -35,6 +35,8 @@ class FusedTrainStep:
         dev = next(model_coarse.parameters()).device
         self.rng_state = _ops.new_rng_state(seed, dev, first_iteration)
         self.loss3 = None
+        self.draw_view = bool(draw_view)   # True: the iteration's training view is drawn in the kernel too (else: selector.view)
+        self.zero_in_step = True     # False: the optimizer leaves the gradient bucket cleared (FlatAdam(zero_grads=True))
 
     @staticmethod
     def applicable(model_coarse, model_fine, options, encode_position_fn, encode_direction_fn, num_rays):
@@ -51,7 +53,8 @@ class FusedTrainStep:
         moment its backward is enqueued - FlatGradBucket.segment_ready - and finished by bucket.all_reduce_mean())."""
         mc, mf = self.models
         mc._grad_sink.forward_issued(); mf._grad_sink.forward_issued()
-        self.bucket.zero()
+        if self.zero_in_step:
+            self.bucket.zero()
         self.forward_and_fine_backward(_zero=False)
         mf._grad_sink.backward_done()     # (world > 1: the fine network's all-reduce starts here, under the coarse half)
         self.coarse_backward()
@@ -63,13 +66,13 @@ class FusedTrainStep:
     def forward_and_fine_backward(self, _zero=True):
         mc, mf = self.models
         sel = self.selector
-        rays, target = _ops.select_rays_draw(sel.height, sel.width, sel.cams, sel.view, sel.near, sel.far, self.rng_state, self.num_rays,
-                                             sel.images)
+        rays, target = _ops.select_rays_draw(sel.height, sel.width, sel.cams, None if self.draw_view else sel.view, sel.near, sel.far,
+                                             self.rng_state, self.num_rays, sel.images)
         pc, pf, prec = _ops.pack_train_pair(mc, mf, self.logs)
         maps, saved = _ops.render_rays_train(pc, pf, rays, self.nc, self.nf, self.lindisp, self.noise_std, self.white, [], None, prec=prec,
                                              rng_state=self.rng_state, perturb=self.perturb)
         self.loss3, g_c, g_f = _ops.mse2_loss(maps[0], maps[3], target, self.luminance, self.rng_state)
-        if _zero:
+        if _zero and self.zero_in_step:
             self.bucket.flat.zero_()
         views_c, views_f = mc._grad_sink.views(mc), mf._grad_sink.views(mf)
         if views_c is None or views_f is None:
@@ -103,6 +106,9 @@ class GraphedTrainStep:
 
     def __init__(self, fused, optimizer, eager_iterations=3, use_graphs=True):
         self.fused, self.opt, self.bucket = fused, optimizer, fused.bucket
+        if getattr(optimizer, "zero_grads", False):
+            self.bucket.flat.zero_()
+            fused.zero_in_step = False      # every step ends with the bucket cleared
         self.eager_left = int(eager_iterations)
         self.use_graphs = bool(use_graphs)
         self.graphs = None

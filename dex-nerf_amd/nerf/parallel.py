@@ -83,7 +83,8 @@ class FlatGradBucket:
         self.params = [p for m in self.modules for p in m.parameters() if p.requires_grad]
         self.overlap = bool(overlap)
         dev = self.params[0].device
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        n_flat = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros((n_flat + 3) // 4 * 4, dtype=torch.float32, device=dev)   # (whole float4s: nerf.FlatAdam)
         self.segments, self._views, off = [], [], 0
         for idx, m in enumerate(self.modules):
             lo = off
@@ -101,6 +102,21 @@ class FlatGradBucket:
         for p, v in zip(self.params, self._views):
             if p.grad is not v:
                 p.grad = v
+
+    def flatten_parameters(self):
+        """Move the parameters themselves into ONE contiguous fp32 buffer laid out like `flat` (every Parameter keeps its identity;
+        its storage becomes a view of `flat_params`) - what nerf.FlatAdam steps in one elementwise pass.  Returns the buffer."""
+        if getattr(self, "flat_params", None) is None:
+            self.flat_params = torch.zeros_like(self.flat)
+            off = 0
+            for p in self.params:
+                view = self.flat_params[off: off + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                off += p.numel()
+            from .models import mark_parameters_updated
+            mark_parameters_updated()      # (the packed-weight caches are keyed on the old storages' versions)
+        return self.flat_params
 
     def zero(self):
         """One memset; re-point any `.grad` something else dropped or replaced.  May be called before the forward or - as the
@@ -193,3 +209,84 @@ def broadcast_parameters(modules, src=0):
             dist.broadcast(t.data, src)
     from .models import mark_parameters_updated
     mark_parameters_updated()
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam (the reference's optimizer: train_dexnerf_rgb.py:146-148, default betas / eps, no weight decay, amsgrad
+    off) over a FlatGradBucket whose parameters have been flattened: ONE launch (dn_adam_step) instead of torch's multi-tensor
+    kernels over 48 tensors.  The step count lives on the device and the kernel advances it, so a captured step replays correctly.
+
+    lr: a float; a device scalar tensor (the caller writes its schedule into it); or, with lr_decay_steps, the reference's schedule
+    lr * lr_decay_factor ** (step / lr_decay_steps) (train_dexnerf_rgb.py:284-289) evaluated inside the kernel - nothing is written
+    from the host between iterations.  zero_grads=True clears the gradients in the same pass (optimizer.zero_grad(), :281).
+    state_dict() / load_state_dict() use torch.optim.Adam's format (per-parameter step / exp_avg / exp_avg_sq), so checkpoints move
+    between the two."""
+
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, lr_decay_factor=None, lr_decay_steps=None, zero_grads=False):
+        self.bucket = bucket
+        self.flat_params = bucket.flatten_parameters()
+        dev = self.flat_params.device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdam: the flat optimizer step is a HIP kernel (dn_adam_step); use torch.optim.Adam on the CPU")
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=True,
+                        differentiable=False, fused=True)
+        super().__init__(bucket.params, defaults)
+        self.exp_avg = torch.zeros_like(self.flat_params)
+        self.exp_avg_sq = torch.zeros_like(self.flat_params)
+        # dn_adam_step's state record: float [steps taken, ticket, last lr, -], then double [beta1^t, beta2^t, decay^t]
+        self.step_state = torch.zeros(12, dtype=torch.float32, device=dev)[:10]
+        self.lr_decay_per_step = float(lr_decay_factor) ** (1.0 / float(lr_decay_steps)) if lr_decay_steps else 1.0
+        self._set_step(0)
+        self.zero_grads = bool(zero_grads)
+        off = 0
+        for p in bucket.params:
+            n = p.numel()
+            self.state[p] = dict(step=self.step_state[0], exp_avg=self.exp_avg[off: off + n].view_as(p),
+                                 exp_avg_sq=self.exp_avg_sq[off: off + n].view_as(p))
+            off += n
+
+    def _set_step(self, t):
+        """Put the state record at `t` steps taken (a fresh optimizer, a loaded checkpoint): the running products in closed form."""
+        b1, b2 = self.param_groups[0]["betas"]
+        self.step_state[0] = float(t)
+        self.step_state[1] = 0.0
+        self.step_state[4:10].view(torch.float64).copy_(torch.tensor([b1 ** t, b2 ** t, self.lr_decay_per_step ** t], dtype=torch.float64))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import _ops
+        if closure is not None:
+            raise RuntimeError("FlatAdam.step: closures are not supported")
+        group = self.param_groups[0]
+        lr = group["lr"]
+        b = self.bucket
+        for p, v in zip(b.params, b._views):
+            if p.grad is not v:
+                raise RuntimeError("FlatAdam.step: a parameter's .grad is no longer the FlatGradBucket's view")
+        _ops.adam_step(self.flat_params, b.flat, self.exp_avg, self.exp_avg_sq, self.step_state, lr, self.lr_decay_per_step,
+                       group["betas"], group["eps"], self.zero_grads)
+        from .models import mark_parameters_updated
+        mark_parameters_updated()       # (in-place writes through the flat buffer do not bump the parameters' versions)
+
+    def last_lr(self):
+        """The learning rate the latest step used (a host read)."""
+        return float(self.step_state[2])
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.Adam's format: the moment estimates are copied INTO the flat buffers (the base class would replace the views)."""
+        groups = state_dict["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.bucket.params):
+            raise ValueError("FlatAdam.load_state_dict: one parameter group over the bucket's parameters expected")
+        steps = 0
+        for idx, p in zip(groups[0]["params"], self.bucket.params):
+            st = state_dict["state"].get(idx)
+            if st is None:
+                continue
+            self.state[p]["exp_avg"].copy_(st["exp_avg"])
+            self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
+            steps = int(float(st["step"]))
+        for key in ("betas", "eps"):
+            self.param_groups[0][key] = groups[0][key]
+        self._set_step(steps)
+        if not torch.is_tensor(groups[0]["lr"]):
+            self.param_groups[0]["lr"] = groups[0]["lr"]

@@ -158,6 +158,8 @@ def main(argv=None):
     ap.add_argument("--autograd-step", action="store_true",
                     help="run the iteration as torch ops + autograd over the fused kernels (torch.randperm / rand / randn draws, mse_loss, "
                          "loss.backward()) instead of nerf.FusedTrainStep")
+    ap.add_argument("--torch-adam", action="store_true",
+                    help="step torch.optim.Adam (fused, multi-tensor) instead of the flat one-launch Adam of this build (nerf.FlatAdam)")
     ap.add_argument("--no-hip-graph", action="store_true",
                     help="launch every kernel of an iteration from Python instead of replaying one captured HIP graph "
                          "(single-GPU runs capture by default: the as-shipped 4x128 nets at 1024 rays are launch-bound)")
@@ -211,16 +213,29 @@ def main(argv=None):
     torch.manual_seed(args.seed + 1000 + rank)
     bucket = parallel.FlatGradBucket(student)
     use_graph = not args.no_hip_graph         # (world > 1: graphs around the exchange, nerf.GraphedTrainStep; the autograd step only with one rank)
-    lr_t = torch.tensor(args.lr, dtype=torch.float32, device=dev)   # a device scalar: the schedule is applied by fill_()
-    opt = torch.optim.Adam(bucket.params, lr=lr_t, fused=True, capturable=True)
+    # The whole iteration on this library's kernels (nerf.FusedTrainStep: pixel draw, jitter, resampling and density noise drawn
+    # inside the kernels, loss head + upstream gradients in one launch, no autograd graph) wherever the fused training kernels
+    # cover the configuration; --autograd-step keeps the torch composition (torch.randperm / rand / randn, autograd).
+    fused_ok = (not args.autograd_step and not args.ndc
+                and nerf.FusedTrainStep.applicable(student[0], student[1], cfg, ex, ed, args.num_random_rays))
+    flat_adam = fused_ok and not args.torch_adam
+    lr_t = torch.tensor(args.lr, dtype=torch.float32, device=dev)   # (torch's Adam) a device scalar: the schedule is applied by fill_()
+    if flat_adam:
+        # Adam over ONE flat parameter buffer: one launch, the learning-rate schedule evaluated inside it, the gradients cleared
+        # in the same pass (reference: torch.optim.Adam + zero_grad + the schedule, train_dexnerf_rgb.py:146-148, 280-289)
+        opt = nerf.FlatAdam(bucket, lr=args.lr, lr_decay_factor=args.lr_decay_factor, lr_decay_steps=args.lr_decay * 1000, zero_grads=True)
+    else:
+        opt = torch.optim.Adam(bucket.params, lr=lr_t, fused=True, capturable=True)
     start = 0
     if args.load_checkpoint:
         ck = torch.load(args.load_checkpoint, map_location=dev)
         student[0].load_state_dict(ck["model_coarse_state_dict"])
         student[1].load_state_dict(ck["model_fine_state_dict"])
+        nerf.models.mark_parameters_updated()
         opt.load_state_dict(ck["optimizer_state_dict"])
-        for group in opt.param_groups:
-            group["lr"] = lr_t
+        if not flat_adam:
+            for group in opt.param_groups:
+                group["lr"] = lr_t
         start = ck["iter"]
     train_ids = data["train"][rank::world] or [data["train"][rank % len(data["train"])]]
     # All training cameras + images live on the device and the view is a device scalar: from pixel draws to packed ray rows
@@ -230,13 +245,10 @@ def main(argv=None):
                                          args.near, args.far,
                                          images=torch.stack([images[v].reshape(hw[0], hw[1], 3) for v in train_ids]), device=dev)
     loss_t = torch.zeros((), dtype=torch.float32, device=dev)
-    # The whole iteration on this library's kernels (nerf.FusedTrainStep: pixel draw, jitter, resampling and density noise drawn
-    # inside the kernels, loss head + upstream gradients in one launch, no autograd graph) wherever the fused training kernels
-    # cover the configuration; --autograd-step keeps the torch composition (torch.randperm / rand / randn, autograd).
     fused = None
-    if not args.autograd_step and nerf.FusedTrainStep.applicable(student[0], student[1], cfg, ex, ed, args.num_random_rays) and not args.ndc:
+    if fused_ok:
         fused = nerf.FusedTrainStep(student[0], student[1], selector, cfg, bucket, ex, ed, args.num_random_rays, seed=args.seed + 7919 * rank,
-                                    luminance=args.ir, first_iteration=start)
+                                    luminance=args.ir, first_iteration=start, draw_view=True)
     graphed = nerf.GraphedTrainStep(fused, opt, eager_iterations=3, use_graphs=use_graph) if fused is not None else None
     use_graph = use_graph and world == 1      # (the autograd step's single graph below: one rank only)
 
@@ -270,9 +282,11 @@ def main(argv=None):
     t_steady = None
     loss_val = psnr = float("nan")
     for it in range(start, args.iters):
-        selector.view.fill_(int(np.random.randint(len(train_ids))))                 # one random training view per iteration
+        if fused is None:                                                            # (the fused step draws its view in the kernel)
+            selector.view.fill_(int(np.random.randint(len(train_ids))))              # one random training view per iteration
         lr = args.lr * args.lr_decay_factor ** (it / (args.lr_decay * 1000))         # train_dexnerf_rgb.py:284-289
-        lr_t.fill_(lr)
+        if not flat_adam:
+            lr_t.fill_(lr)
         if it == start + 20:                   # past the eager iterations and the capture: the steady part is timed from here
             torch.cuda.synchronize()
             t_steady = time.perf_counter()

@@ -11,7 +11,7 @@ F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-func
 make -C $C -j8 >/dev/null
 mkdir -p $REPO/exp_libs $C/build/exp_$NAME
 OBJS=""
-for s in api.cpp rays_sampling.hip composite.hip val_metrics.hip mlp_fused.hip mlp_fused48.hip mlp_train.hip; do
+for s in api.cpp rays_sampling.hip composite.hip val_metrics.hip mlp_fused.hip mlp_fused48.hip mlp_train.hip mlp_train48.hip optimizer.hip; do
   if echo " $FILES " | grep -q " $s "; then
     /opt/rocm/bin/hipcc $F $FLAGS -I$C -x hip -c $C/$s -o $C/build/exp_$NAME/$s.o &
     OBJS="$OBJS $C/build/exp_$NAME/$s.o"

@@ -1545,6 +1545,64 @@ def test_bench_multi_gpu_leg_rehearsal_two_ranks_one_gpu(dev):
     assert rs["n_gpus"] == 2 and rs["render_sharded_ms"] > rs["all_gather_ms"] > 0 and rs["gathered_bytes_per_rank"] == 800 * 800 * 4 * (10 + 20)
 
 
+def test_flat_adam_against_torch_adam(dev):
+    """nerf.FlatAdam (dn_adam_step: one launch over flat parameter / gradient / moment buffers, the step count and the reference's
+    learning-rate schedule inside the kernel) against torch.optim.Adam in float64 on the same gradients for 25 steps
+    (reference: train_dexnerf_rgb.py:146-148, 280-289): parameters and both moments within 2e-6 relative; the gradients are
+    cleared by the step; torch.optim.Adam's state_dict format round-trips in both directions."""
+    import nerf
+    from nerf import parallel
+    torch.manual_seed(3)
+    mkw = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+    nets = [nerf.models.FlexibleNeRFModel(**mkw).to(dev) for _ in range(2)]
+    ref_params = [p.detach().double().cpu().clone().requires_grad_(True) for m in nets for p in m.parameters()]
+    bucket = parallel.FlatGradBucket(nets)
+    lr0, factor, steps_decay = 5e-3, 0.1, 40.0
+    opt = nerf.FlatAdam(bucket, lr=lr0, lr_decay_factor=factor, lr_decay_steps=steps_decay, zero_grads=True)
+    for p, q in zip(bucket.params, ref_params):
+        assert p.data_ptr() >= opt.flat_params.data_ptr() and torch.equal(p.detach().cpu().double(), q.detach())   # flattened in place
+    ref = torch.optim.Adam(ref_params, lr=lr0)
+    t32_params = [q.detach().float().to(dev).requires_grad_(True) for q in ref_params]       # torch's own fp32 fused Adam: the yardstick
+    t32 = torch.optim.Adam(t32_params, lr=lr0, fused=True)
+    gen = torch.Generator().manual_seed(5)
+    for it in range(25):
+        for o in (ref, t32):
+            for group in o.param_groups:
+                group["lr"] = lr0 * factor ** (it / steps_decay)
+        for p, q, t in zip(bucket.params, ref_params, t32_params):
+            g = torch.randn(q.shape, generator=gen, dtype=torch.float64) * (10.0 ** float(torch.randint(-6, 1, (1,), generator=gen)))
+            q.grad = g.clone()
+            p.grad.copy_(g.float())
+            t.grad = g.float().to(dev)
+        opt.step()
+        ref.step()
+        t32.step()
+        assert float(bucket.flat.abs().max()) == 0.0                       # zero_grads: the bucket is clean for the next iteration
+    assert float(opt.step_state[0]) == 25.0 and abs(opt.last_lr() - lr0 * factor ** (24 / steps_decay)) < 1e-9
+
+    def rel(a, b):
+        return float((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    worst = [0.0, 0.0]
+    for p, q, t in zip(bucket.params, ref_params, t32_params):
+        st, rt, tt = opt.state[p], ref.state[q], t32.state[t]
+        for mine, theirs, torch32 in ((p.detach(), q.detach(), t.detach()), (st["exp_avg"], rt["exp_avg"], tt["exp_avg"]),
+                                      (st["exp_avg_sq"], rt["exp_avg_sq"], tt["exp_avg_sq"])):
+            e_mine, e_t32 = rel(mine, theirs), rel(torch32, theirs)
+            worst = [max(worst[0], e_mine), max(worst[1], e_t32)]
+            assert e_mine < max(1.5 * e_t32, 1e-6), (e_mine, e_t32)      # as close to float64 Adam as torch's fp32 kernel is
+    _record_measurement("flat_adam_rel_err_vs_f64", dict(mine=worst[0], torch_fp32_fused=worst[1]))
+    # checkpoints move between the two optimizers
+    sd = opt.state_dict()
+    t_params = [p.detach().clone().requires_grad_(True) for p in bucket.params]
+    t_opt = torch.optim.Adam(t_params, lr=lr0)
+    t_opt.load_state_dict(sd)
+    assert float(t_opt.state[t_params[0]]["step"]) == 25.0
+    nets2 = [nerf.models.FlexibleNeRFModel(**mkw).to(dev) for _ in range(2)]
+    opt2 = nerf.FlatAdam(parallel.FlatGradBucket(nets2), lr=lr0)
+    opt2.load_state_dict(t_opt.state_dict())
+    assert float(opt2.step_state[0]) == 25.0 and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+
+
 # ---- the draws of a training iteration made on the device (csrc/dn_rng.h, nerf.FusedTrainStep) ---------------------------------
 def test_device_pixel_draw_is_a_permutation_with_uniform_marginals(dev):
     """dn_select_rays_draw: the pixels of an iteration are a keyed permutation of the H W pixels, so ANY prefix is a draw without
@@ -1590,6 +1648,25 @@ def test_device_pixel_draw_is_a_permutation_with_uniform_marginals(dev):
     dof = h * w - 1
     assert abs(chi2 - dof) < 5.0 * (2 * dof) ** 0.5, (chi2, dof)
     assert int(counts.min()) > 0.8 * expect and int(counts.max()) < 1.2 * expect
+    # view = None: the training view is drawn in the kernel as well (np.random.choice(i_train), train_dexnerf_rgb.py:223): one
+    # view per iteration (all rays of a draw come from it), every view about equally often, rows equal to the explicit-view call
+    n_views = 5
+    cams5 = cams[:1].repeat(n_views, 1).contiguous()
+    cams5[:, 9] = torch.arange(n_views, device=dev, dtype=torch.float32)          # the camera position tells the views apart
+    imgs5 = torch.rand(n_views, h, w, 3, device=dev)
+    st = _ops.new_rng_state(9, dev)
+    seen = torch.zeros(n_views, dtype=torch.int64)
+    for it in range(1000):
+        rays, target, pix = _ops.select_rays_draw(h, w, cams5, None, 2.0, 6.0, st, 64, imgs5, want_pixels=True)
+        v = rays[:, 0]
+        assert float(v.min()) == float(v.max())
+        vi = int(v[0])
+        seen[vi] += 1
+        if it < 5:
+            ref_rays, ref_target = _ops.select_rays_indirect(h, w, cams5, torch.tensor(vi, dtype=torch.int32, device=dev), 2.0, 6.0, pix, imgs5)
+            assert torch.equal(rays, ref_rays) and torch.equal(target, ref_target)
+        _ops.mse2_loss(dummy[:64], dummy[:64], dummy[:64], rng_state=st)
+    assert int(seen.min()) > 150 and int(seen.max()) < 250, seen      # 200 expected, sigma 12.6
 
 
 def test_in_kernel_uniforms_and_normals(dev):

@@ -67,7 +67,7 @@ def test_argument_validation_needs_no_gpu(hiplib):
                                        null, null, null, null, null, null, null, null, null, null, null, null, null, null,
                                        null, null, null, 0, null) == 0     # zero rays: nothing to do
     # the device-side draws of a training iteration: argument checks (no launch without a GPU)
-    assert hiplib.dn_select_rays_draw(4, 4, null, null, 2.0, 6.0, null, 4, null, 0, null, null, null, null) == -1000
+    assert hiplib.dn_select_rays_draw(4, 4, null, null, 0, 2.0, 6.0, null, 4, null, 0, null, null, null, null) == -1000
     assert hiplib.dn_mse2_loss(null, null, null, 4, 0, null, null, null, null, null) == -1000
     assert hiplib.dn_rng_fill(null, 0, 4, 0, null, null) == -1000 and hiplib.dn_rng_fill(null, 0, 0, 0, null, null) == 0
     # 8-bit saved tensors (DN_PREC_BF16_S8): the same tiles at one 1 KiB unit per PAIR of bf16 pieces; bf16 arithmetic only

@@ -748,6 +748,25 @@ __device__ __forceinline__ void dma16_lanes(const void* src_lane, unsigned lds_a
       : "memory");
 }
 
+// 4 B per lane for lanes 0-47 (a 48-point wave tile's input row): the lane mask is set and restored inside the statement, so the
+// caller stays straight-line code (every lane is active where this is used)
+__device__ __forceinline__ void dma4_lanes48(const void* src_lane, unsigned lds_addr) {
+  const unsigned lds = __builtin_amdgcn_readfirstlane(lds_addr);
+  const void* src = src_lane;
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %[keep], m0\n\t"
+      "s_mov_b32 m0, %[lds]\n\t"
+      "s_mov_b32 exec_hi, 0xffff\n\t"
+      "s_nop 1\n\t"
+      "global_load_lds_dword %[vaddr], off\n\t"
+      "s_mov_b32 exec_hi, -1\n\t"
+      "s_mov_b32 m0, %[keep]"
+      : [keep] "=&s"(keep)
+      : [lds] "s"(lds), [vaddr] "v"(src)
+      : "memory");
+}
+
 // ---- positional encoding straight into B-piece layout -------------------------------------------------
 // Slot u of this lane-half (mlp_layout.h pe_slot_col): u < 6*(L/2): sin/cos of this half's frequencies;
 // then identity (half 0: x, y; half 1: z); rest zero padding.

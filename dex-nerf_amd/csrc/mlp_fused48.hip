@@ -43,9 +43,19 @@ __device__ __forceinline__ void rotate3(const float (&x)[3], int g, float (&xr)[
 // SAVE = 2: the training forward of DN_PREC_BF16_S8 - the same chain also streams every stage's output (and both encodings) as
 // e4m3 units in the s8-48 layout and the ReLU mask words (mlp_geo48.h) to HBM: non-temporal scalar-base 16-byte stores
 // (mlp_device.h store16_uniform), a unit every fourth output tile per point group.
-template <int W, int F, int DC = 0, unsigned MASKC = 0, int VIEWC = 0, int SAVE = 0>
+// OVLP = 1 (the as-shipped 4 x 128 instance, rays + depths as inputs): the xyz encoding of tile t + 1 is computed inside tile t -
+// one slot per output tile of the first two trunk stages, in the shadow of their MFMAs - instead of in a block at the top of
+// tile t + 1 during which the matrix pipes idle (18 % of this instance's pass: profiles/r02_config_sweep.md).  This instance has
+// the registers for it (the W = 256 one does not: 13 carried VGPRs + the encoding table held in 38): the rotated coordinates of
+// the next tile's points are read from the input rows after layer1, the pieces are parked in the (by then dead) LDS stash.
+template <int W, int F, int DC = 0, unsigned MASKC = 0, int VIEWC = 0, int SAVE = 0, int OVLP = 0>
 __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdParams p, G48Params q) {
   static_assert(SAVE == 0 || (SAVE == 2 && F == 1), "saved tensors: the 8-bit layout, bf16 arithmetic");
+  constexpr bool OVL = OVLP != 0;
+  static_assert(!OVL || (DC >= 3 && MASKC == 0u && VIEWC != 0 && SAVE == 0 && W == 128),
+                "overlapped encoding: fixed shape, no skip layer (the stash is dead after layer1), two trunk stages of 24 output tiles");
+  constexpr int VSETS = OVL ? 3 : 2;           // view-direction row sets: the inputs of tile t + 2 arrive during tile t
+  constexpr int IN_ROWS = 7 + 3 * VSETS;
   constexpr bool FIXED = DC > 0;
   constexpr bool ST = !FIXED;   // settle at stage ends
   constexpr bool CL = SAVE != 0;   // clamp stage outputs to e4m3's range (emit48)
@@ -83,7 +93,8 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
   // (the next tile is staged at the top of this one, when registers are free; the view direction of THIS tile is only
   // consumed near its end, so those rows alternate between two sets)
   float* inbuf = reinterpret_cast<float*>(smem + kRingBytes + q.bias_bytes + kG48TableBytes + WAVES * PT * KXP * kPieceBytes) +
-                 wave * (kG48InRows * PPW);   // wave-uniform
+                 wave * (IN_ROWS * PPW);   // wave-uniform
+  static_assert(OVL || IN_ROWS == kG48InRows, "g48_lds_bytes sizes the input rows");
 
   // inputs of a tile by 4-byte LDS-DMA: lane l < 48 stages point l of this wave (mlp_fused.hip issue_inputs)
   // 32-bit point indices throughout (the dispatcher sends launches of >= 2^31 - 1024 points to the 32-point kernel): the
@@ -124,6 +135,20 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     for (int i = threadIdx.x; i < (q.bias_bytes + kG48TableBytes) / 16; i += WAVES * 64) l[i] = gsrc[i];
   }
   issue_inputs(blockIdx.x, 0);
+  // OVL: the same DMAs without control flow (mid-pass a branch is a merge point the compiler may park copies of in-flight weight
+  // fragments at): the lane mask is set inside the asm statement, the tile index is clamped by the caller
+  const unsigned inbuf_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)inbuf));
+  auto issue_inputs_flat = [&](int tile, int set) {
+    const int ln = fresh_lane();
+    int pt = tile * PPG + wave * PPW + ln;
+    pt = pt < n_points ? pt : n_points - 1;
+    const float* r = p.rays + static_cast<long long>(pt / p.S) * p.ray_stride;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) dma4_lanes48(r + c, inbuf_addr + c * (PPW * 4));
+    dma4_lanes48(p.z + pt, inbuf_addr + 6 * (PPW * 4));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dma4_lanes48(r + 8 + c, inbuf_addr + (7 + c) * (PPW * 4) + set * (3 * PPW * 4));
+  };
 
   Pipe<WAVES> pipe;
   pipe.ring = ring;
@@ -159,9 +184,24 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
   unsigned trk = 0;   // fp16 instances: running maximum of the stage inputs' 16-bit patterns (run_stage48, TRK)
-  int vset = 0;  // which view-direction rows hold this tile's directions (wave-uniform, flips every tile)
+  int vset = 0;  // which view-direction rows hold this tile's directions (wave-uniform, next set every tile)
+  // OVL: this lane group's 16 xyz table entries in registers for the whole kernel (a slot mid-stage must not read LDS: the
+  // compiler would wait with lgkmcnt(0) and drain the weight-fragment reads in flight).  Slots >= 3 are pure sines - or padding,
+  // frequency 0 and phase 0: sin(0) = 0 - only slots 0-2 can be identity columns (lane group 0) and keep their two weights.
+  float tfreq[OVL ? 16 : 1], tphase[OVL ? 16 : 1], tw_id[3], tw_sin[3];
+  float xr_n[PT][3];   // OVL: the next tile's three points of this lane, rotated for its lane group
+  BP8 encp;            // OVL: the piece being assembled
+  if constexpr (OVL) {
+    const f32x4* tabx = reinterpret_cast<const f32x4*>(tab_lds) + (lane >> 4) * 16;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const f32x4 e = tabx[u];
+      tfreq[u] = e[0]; tphase[u] = e[1];
+      if (u < 3) { tw_id[u] = e[2]; tw_sin[u] = e[3]; }
+    }
+  }
   const int n_tiles = static_cast<int>(p.n_tiles);
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, vset ^= 1) {
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, vset = (VSETS == 2 ? vset ^ 1 : (vset == 2 ? 0 : vset + 1))) {
     // training forward: this wave's three point groups' saved-unit bases and its mask words' (s8-48 layout, mlp_geo48.h) - wave-
     // uniform, kept in scalar registers for the tile; every store adds a small offset (store16_uniform_at)
     const char* act_grp[PT] = {nullptr, nullptr, nullptr};
@@ -176,7 +216,9 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       mask_base = uniform_ptr(p.masks + wt * p.mask_words * (2 * kPieceBytes));
     }
     // ---- xyz encoding of this lane's three points, its 16 columns each, into the per-wave LDS stash ----
-    {
+    // (OVL: only a workgroup's first tile is encoded here; every later one was encoded during the tile before it)
+    const bool first_tile = tile == static_cast<int>(blockIdx.x);
+    if (!OVL || first_tile) {
       const int ln = fresh_lane();
       const int j = ln & 15;
       const f32x4* tabx = reinterpret_cast<const f32x4*>(tab_lds) + (ln >> 4) * 16;
@@ -313,6 +355,54 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 #if defined(DN_STAMP) && DN_STAMP == 4
     pipe.template stage_end<0>();
 #endif
+    if constexpr (OVL) {
+      // the next tile's inputs - their DMAs were issued a whole tile ago (the first tile's: at its top) - become this lane's three
+      // rotated points, then the rows are handed to the DMAs of the tile after next.  Waves 4-7 issue no weight DMAs, so no counted
+      // wait of theirs pushes input DMAs through: they wait here (as does everyone on a workgroup's first tile).  The branch
+      // lives inside the asm statement: the compiler sees straight-line code.
+      {
+        const unsigned must_wait = __builtin_amdgcn_readfirstlane((wave >= 4 || first_tile) ? 1u : 0u);
+        asm volatile("s_cmp_eq_u32 %0, 0\n\t"
+                     "s_cbranch_scc1 .Ldn_ovl_nowait%=\n\t"
+                     "s_waitcnt vmcnt(0)\n"
+                     ".Ldn_ovl_nowait%=:" ::"s"(must_wait) : "scc", "memory");
+      }
+      const int ln = fresh_lane();
+      const int j = ln & 15;
+      float in[PT][7];
+#pragma unroll
+      for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int c = 0; c < 7; ++c) in[t][c] = inbuf[c * PPW + t * 16 + j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      {
+        const int t2 = tile + 2 * static_cast<int>(gridDim.x);
+        issue_inputs_flat(t2 < n_tiles ? t2 : tile, vset == 0 ? 2 : vset - 1);   // rows 0-6 are free again; view set (vset + 2) % 3
+      }
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        float x[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[c] = in[t][c] + in[t][3 + c] * in[t][6];   // plain mul then add (train_utils.py:136)
+        rotate3(x, ln >> 4, xr_n[t]);
+      }
+    }
+    // one encoding slot of the next tile (OVL): M = 0 .. 47 in the order the first two trunk stages emit their output tiles
+    auto enc_step = [&](auto m_c) {
+      if constexpr (OVL) {
+        constexpr int m = decltype(m_c)::value;
+        constexpr int tq = m / 16, k = (m % 16) / 8, e = m % 8, u = k * 8 + e;
+        static_assert(KXP == 2 && PT == 3, "48 slots per lane");
+        const float xc = xr_n[tq][u % 3];
+        const float arg = xc * tfreq[u];                                            // (pe_value, op for op)
+        const float rev = __builtin_amdgcn_fractf(arg * 0.15915494309189535f) + tphase[u];
+        const float sv = __builtin_amdgcn_sinf(rev);
+        float val = sv;
+        if constexpr (u < 3) val = tw_id[u] * xc + tw_sin[u] * sv;
+        encp[e] = static_cast<Elem>(val);
+        if constexpr (e == 7) *reinterpret_cast<BP8*>(pex_of(fresh_lane()) + (tq * KXP + k) * kPieceBytes) = encp;
+      }
+    };
     float out4[PT][4];
     // ---- heads on the trunk output hx (hy: the other, by then free, activation set) ----
     auto heads = [&](const BP8 (&hx)[PT][KH], BP8 (&hy)[PT][KH], auto view_c) __attribute__((always_inline)) {
@@ -334,6 +424,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         __builtin_amdgcn_sched_barrier(0);
         // (one point group at a time, into the xyz stash - dead once the trunk is done - so that neither the block's
         // temporaries nor the pieces themselves compete with the 96 registers of fc_feat's output)
+        BP8 ped_now[PT];
         {
           const int ln = fresh_lane();
           const int j = ln & 15;
@@ -349,7 +440,8 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
             BP8 piece;
 #pragma unroll
             for (int e = 0; e < 8; ++e) piece[e] = static_cast<Elem>(pe_value(vr[e % 3], tabd[e]));
-            *reinterpret_cast<BP8*>(pex + t * kPieceBytes) = piece;
+            if constexpr (OVL) ped_now[t] = piece;   // (the stash holds the NEXT tile's xyz pieces by now: same lane, no need to park)
+            else *reinterpret_cast<BP8*>(pex + t * kPieceBytes) = piece;
             if constexpr (SAVE != 0) {
               // one piece = 8 bytes per lane: lanes of groups 0 / 1 store [their own 8 bytes | those of groups 2 / 3] (the upper
               // half of the unit's rows is then a copy nobody reads) - one 32-feature fragment for the weight-gradient kernel
@@ -368,7 +460,10 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         BP8 bg[PT][KH / 2];
         BP8 ped[PT];
 #pragma unroll
-        for (int t = 0; t < PT; ++t) ped[t] = *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes);
+        for (int t = 0; t < PT; ++t) {
+          if constexpr (OVL) ped[t] = ped_now[t];
+          else ped[t] = *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes);
+        }
         auto pe_dir = [&](int t, int) { return ped[t]; };
         mask_clear();
         run_stage48<F, NT / 2, KH, KDP, POS_D, false, ST, 0, PH, 1>(pipe, hy, pe_dir, bias_at(bias_tile), 0u, [&](auto nt_c, auto t_c, const f32x4& acc) {
@@ -413,6 +508,10 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
           emit48<F, true, decltype(nt_c)::value, CL>(acc, bout[decltype(t_c)::value]);
           mask_tail(nt_c, t_c, bout[decltype(t_c)::value]);
           unit_tail(nt_c, t_c, bout[decltype(t_c)::value], p.slot_trunk0 + i * KHU);
+          if constexpr (OVL && i < 2) {
+            static_assert(!OVL || NT * PT == 24, "two trunk stages = the 48 encoding slots of a lane");
+            enc_step(std::integral_constant<int, i * 24 + decltype(nt_c)::value * PT + decltype(t_c)::value>{});
+          }
         };
         mask_clear();
         if constexpr ((MASKC >> i) & 1u) {
@@ -636,7 +735,7 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
   G48Params q{};
   q.base = region; q.bias_bytes = L.bias_bytes; q.total_pieces = L.total_pieces;
   p.n_tiles = (p.n_points + kG48PointsPerWg - 1) / kG48PointsPerWg;
-  const size_t lds = g48_lds_bytes(L);
+  size_t lds = g48_lds_bytes(L);
   if (lds > 160 * 1024) { set_error("mlp_forward48: %zu bytes of LDS", lds); return DN_E_UNSUPPORTED; }
   const int cus = device_cus();
   const long long grid = p.n_tiles < cus ? p.n_tiles : cus;
@@ -691,6 +790,13 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
     if (paper && fixed_ok) return launch(mlp_forward48_kernel<256, 1, 8, 0x10u, 1, 2>);
     if (shipped && fixed_ok) return launch(mlp_forward48_kernel<128, 1, 4, 0u, 1, 2>);
     return d.hidden_size == 256 ? launch(mlp_forward48_kernel<256, 1, 0, 0u, 0, 2>) : launch(mlp_forward48_kernel<128, 1, 0, 0u, 0, 2>);
+  }
+  // the as-shipped nets on rays + depths (the render path): the instance that encodes tile t + 1 inside tile t (a third set of
+  // view-direction rows in LDS)
+  if (shipped && fixed_ok && p.mode == 0 && std::getenv("DEXNERF_G48_NO_OVERLAP") == nullptr) {
+    lds += static_cast<size_t>(kG48Waves) * 3 * kG48PointsPerWave * sizeof(float);
+    if (precision == DN_PREC_F16) return launch(mlp_forward48_kernel<128, 2, 4, 0u, 1, 0, 1>);
+    return launch(mlp_forward48_kernel<128, 1, 4, 0u, 1, 0, 1>);
   }
   if (precision == DN_PREC_F16) {
     if (paper && fixed_ok) return launch(mlp_forward48_kernel<256, 2, 8, 0x10u, 1>);

@@ -25,12 +25,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ param, f
   if (threadIdx.x == 0) {
     // torch (_fused_adam, capturable): bias corrections and step size in double
     sh[0] = lr / (1.0 - b1p);
-    sh[1] = sqrt(1.0 - b2p);
+    sh[1] = 1.0 / sqrt(1.0 - b2p);
   }
   __syncthreads();
   // the hyper-parameters stay doubles, as in torch's kernel: every product with one of them is formed in double and rounded to
   // fp32 once, when the element is stored (an fp32-only update is ~4x further from float64 Adam after 25 steps - measured, tests)
-  const double step_size = sh[0], bc2_sqrt = sh[1];
+  const double step_size = sh[0], inv_bc2_sqrt = sh[1];
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
     const float4 g = grad[i];
     float4 p = param[i], mm = m[i], vv = v[i];
@@ -38,14 +38,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ param, f
       const double gd = static_cast<double>(ge);
       me = static_cast<float>(static_cast<double>(me) + (gd - static_cast<double>(me)) * (1.0 - beta1));   // lerp(exp_avg, grad, 1 - beta1)
       ve = static_cast<float>(static_cast<double>(ve) * beta2 + (1.0 - beta2) * gd * gd);
-      const double denom = static_cast<double>(sqrtf(ve)) / bc2_sqrt + eps;
+      const double denom = static_cast<double>(sqrtf(ve)) * inv_bc2_sqrt + eps;
       pe = static_cast<float>(static_cast<double>(pe) - step_size * static_cast<double>(me) / denom);
     };
     upd(p.x, mm.x, vv.x, g.x); upd(p.y, mm.y, vv.y, g.y); upd(p.z, mm.z, vv.z, g.z); upd(p.w, mm.w, vv.w, g.w);
     param[i] = p; m[i] = mm; v[i] = vv;
     if (zero_grads) grad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
-  __threadfence();
+  // (no fence: the ticket only orders this workgroup's READS of the state - done, their values were used above - before the last
+  // workgroup's write of it; the next launch sees that write through the kernel boundary)
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned* ticket = reinterpret_cast<unsigned*>(state + 1);

@@ -8,6 +8,7 @@ the sum over the 8 XCDs."""
 import csv
 import glob
 import json
+import os
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "fine_net"
@@ -46,7 +47,8 @@ if p.get("fetch") and p.get("write"):
     d["hbm_read_bytes"] = 2.0 * fetch_b
     d["hbm_write_bytes"] = write_b
     d["hbm_bytes_per_launch"] = 2.0 * fetch_b + write_b
-    d["algorithmic_bytes_per_launch"] = 160000 * 192 * 20 + 160000 * 44
+    points = int(os.environ.get("PMC_POINTS", 160000 * 192))
+    d["algorithmic_bytes_per_launch"] = points * 20 + 160000 * 44 if "PMC_POINTS" not in os.environ else points * 20
 if p.get("l2"):
     h, m = p["l2"]["TCC_HIT_sum"], p["l2"]["TCC_MISS_sum"]
     d["l2_hit_rate"] = h / (h + m)

@@ -4,13 +4,15 @@
 # WRITE_SIZE 2 (MI355X_MICROARCH.md, rocprofv3 PMC slots) - asking for both in one pass aborts the profiler with
 # "error code 38: Request exceeds the capabilities of the hardware to collect" (that was round 1's "pass does not complete").
 #   usage: scripts/pmc_fine_net.sh [tag] [ENV=VAL ...]      output: gpurun_out/pmc_<tag>.json (+ per-pass logs / csv)
+# PMC_SCRIPT / PMC_ARGS pick another launch, e.g. the as-shipped 4 x 128 nets' fine launch of config 3 (PMC_POINTS = its points,
+# for the algorithmic bytes):  scripts/pmc_fine_net.sh w128 PMC_SCRIPT=scripts/quick_time128.py "PMC_ARGS=fp16 129600 128" PMC_POINTS=16588800
 tag=${1:-fine_net}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 for kv in "$@"; do export "$kv"; done
 pass() {  # name, counters...
   name=$1; shift
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}_$name -- python3 scripts/quick_time.py bf16 160000 > gpurun_out/pmc_${tag}_$name.log 2>&1 || echo "pass $name failed (see gpurun_out/pmc_${tag}_$name.log)"
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}_$name -- python3 ${PMC_SCRIPT:-scripts/quick_time.py} ${PMC_ARGS:-bf16 160000} > gpurun_out/pmc_${tag}_$name.log 2>&1 || echo "pass $name failed (see gpurun_out/pmc_${tag}_$name.log)"
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE

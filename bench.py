@@ -496,7 +496,12 @@ def main():
                     res = train_dexnerf.main(["--iters", "4000", "--size", "64", "--views", "8", "--num-random-rays", "1024", "--layers", "4",
                                               "--width", "128", "--num-fine", "64", "--validate-every", "0", "--quiet", "--precision", prec])
                     result[key] = {"rays_per_s": res["rays_per_s"], "rays_per_step": 1024, "final_train_psnr_db": res["history"][-1][2],
-                                   "what": f"train_dexnerf.py --precision {prec}, 4x128 nets, 64+64 samples, HIP-graph replay, incl. capture time"}
+                                   "steady_ms_per_iter": res.get("steady_ms_per_iter"),
+                                   "steady_rays_per_s": 1024.0 / (res["steady_ms_per_iter"] * 1e-3) if res.get("steady_ms_per_iter") else None,
+                                   "hip_graphs_per_iter": res.get("hip_graphs"),
+                                   "what": f"train_dexnerf.py --precision {prec}, 4x128 nets, 64+64 samples, nerf.FusedTrainStep + nerf.FlatAdam "
+                                           "replayed as one HIP graph; rays_per_s over all 4000 iterations incl. the eager ones and the capture, "
+                                           "steady_*: from iteration 20 on"}
             except Exception as exc:  # noqa: BLE001
                 result["train_as_shipped"] = {"error": f"{type(exc).__name__}: {exc}"}
             finally:

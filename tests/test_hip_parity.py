@@ -1545,6 +1545,38 @@ def test_bench_multi_gpu_leg_rehearsal_two_ranks_one_gpu(dev):
     assert rs["n_gpus"] == 2 and rs["render_sharded_ms"] > rs["all_gather_ms"] > 0 and rs["gathered_bytes_per_rank"] == 800 * 800 * 4 * (10 + 20)
 
 
+def test_as_shipped_render_instance_with_overlapped_encoding_is_bit_identical(dev):
+    """The as-shipped 4 x 128 nets on rays + depths run the forward instance that encodes tile t + 1 inside tile t's trunk stages
+    (mlp_forward48_kernel<128, F, 4, 0, 1, 0, 1>: csrc/mlp_fused48.hip).  Same arithmetic, another schedule: its output must equal
+    the plain fixed-shape instance's (DEXNERF_G48_NO_OVERLAP=1) bit for bit - one point, ragged tails, one tile, more tiles than
+    workgroups (every workgroup then runs its first-tile prologue and the steady state), bf16 and fp16."""
+    import nerf
+    from nerf import _hip, _ops, synthetic as syn
+    kw = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+    nerf.set_precision("bf16")
+    try:
+        m = nerf.models.FlexibleNeRFModel(**kw)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(43, sigma_bias=-2.0, **kw).items()})
+        m = m.to(dev)
+        for prec in (_hip.PREC_BF16, _hip.PREC_F16):
+            pk = m.packed(precision=prec)
+            for n, s in ((1, 1), (7, 55), (1000, 64), (3000, 128), (70001, 64)):
+                g = torch.Generator(device=dev).manual_seed(n + s)
+                rd = torch.nn.functional.normalize(torch.randn(n, 3, device=dev, generator=g), dim=-1)
+                rays = torch.cat([torch.randn(n, 3, device=dev, generator=g), rd, torch.full((n, 1), 0.3, device=dev),
+                                  torch.full((n, 1), 4.0, device=dev), rd], -1).contiguous()
+                z = torch.sort(torch.rand(n, s, device=dev, generator=g) * 3.7 + 0.3, -1)[0].contiguous()
+                out = _ops.run_network_rays(pk, rays, z)
+                os.environ["DEXNERF_G48_NO_OVERLAP"] = "1"
+                try:
+                    plain = _ops.run_network_rays(pk, rays, z)
+                finally:
+                    os.environ.pop("DEXNERF_G48_NO_OVERLAP", None)
+                assert bool(torch.isfinite(out).all()) and torch.equal(out, plain), (prec, n, s)
+    finally:
+        nerf.set_precision("fp32")
+
+
 def test_flat_adam_against_torch_adam(dev):
     """nerf.FlatAdam (dn_adam_step: one launch over flat parameter / gradient / moment buffers, the step count and the reference's
     learning-rate schedule inside the kernel) against torch.optim.Adam in float64 on the same gradients for 25 steps

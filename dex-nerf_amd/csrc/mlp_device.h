@@ -113,8 +113,17 @@ struct FwdParams {
 // (counted vmcnt, never 0 in the loop); phase p+4 is issued into the slot phase p-1 just vacated.
 // Extra VMEM ops (input DMAs, the output store) are younger or older than the DMAs a wait must cover and,
 // because VMEM ops retire in order, can only make a counted wait stricter, never weaker.
+// Two classes, one source: the 48-point kernels' translation units (mlp_stage48.h sets DN_PIPE_ASM_READS / _LEADER_DMA /
+// _SCALAR_STATE before this header) get Pipe48 - other members, other methods - the 32-point kernels' units get Pipe.  They
+// never share a name: the same class name with two layouts in two translation units of one library would be an ODR violation
+// that only happens to work because device code is compiled per unit.
+#if defined(DN_PIPE_ASM_READS) || defined(DN_PIPE_LEADER_DMA) || defined(DN_PIPE_SCALAR_STATE)
+#define DN_PIPE_CLASS Pipe48
+#else
+#define DN_PIPE_CLASS Pipe
+#endif
 template <int WAVES>
-struct Pipe {
+struct DN_PIPE_CLASS {
   static constexpr int PER_WAVE = kPhasePieces / WAVES;
   char* ring;           // LDS
   unsigned ring_addr;   // its 32-bit LDS byte address (for M0)

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     for (int c = 0; c < 3; ++c) dma4_lanes48(r + 8 + c, inbuf_addr + (7 + c) * (PPW * 4) + set * (3 * PPW * 4));
   };
 
-  Pipe<WAVES> pipe;
+  Pipe48<WAVES> pipe;
   pipe.ring = ring;
   pipe.ring_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)ring));
   pipe.lane16 = lane * 16;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
     dma16_lanes(src + kPieceBytes, dst + kPieceBytes);
   };
 
-  Pipe<WAVES> pipe;
+  Pipe48<WAVES> pipe;
   pipe.ring = ring;
   pipe.ring_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)ring));
   pipe.lane16 = lane * 16;

@@ -701,8 +701,8 @@ int launch_pack48(const dn_mlp_desc& d, int precision, const PackPtrs& ptrs, cha
   fill_freqs(tabs.fx, d.num_encoding_fn_xyz, d.log_sampling_xyz);
   if (d.use_viewdirs) fill_freqs(tabs.fd, d.num_encoding_fn_dir, d.log_sampling_dir);
   tabs.LX = d.num_encoding_fn_xyz; tabs.LD = d.num_encoding_fn_dir;
-  if (precision == DN_PREC_F16) hipLaunchKernelGGL(pack48_kernel<2>, dim3(512), dim3(256), 0, stream, L, ptrs, tabs, region);
-  else hipLaunchKernelGGL(pack48_kernel<1>, dim3(512), dim3(256), 0, stream, L, ptrs, tabs, region);
+  if (precision == DN_PREC_F16) hipLaunchKernelGGL(pack48_kernel<2>, dim3(pack48_blocks(L)), dim3(256), 0, stream, L, ptrs, tabs, region);
+  else hipLaunchKernelGGL(pack48_kernel<1>, dim3(pack48_blocks(L)), dim3(256), 0, stream, L, ptrs, tabs, region);
   return check_launch("mlp_pack48");
 }
 
@@ -724,7 +724,7 @@ int launch_pack48_pair(const dn_mlp_desc& d, const PackPtrs& a, const PackPtrs& 
   if (d.use_viewdirs) fill_freqs(tabs.fd, d.num_encoding_fn_dir, d.log_sampling_dir);
   tabs.LX = d.num_encoding_fn_xyz; tabs.LD = d.num_encoding_fn_dir;
   static_assert(sizeof(NetLayout) + 2 * sizeof(PackPtrs) + sizeof(G48Tables) + 16 <= 4096, "kernel arguments of the pair pack");
-  hipLaunchKernelGGL(pack48_pair_kernel<1>, dim3(256, 2), dim3(256), 0, stream, L, a, b, tabs, region_a, region_b);
+  hipLaunchKernelGGL(pack48_pair_kernel<1>, dim3(pack48_blocks(L), 2), dim3(256), 0, stream, L, a, b, tabs, region_a, region_b);
   return check_launch("mlp_pack48_pair");
 }
 

@@ -108,6 +108,15 @@ inline bool g48_supported(const dn_mlp_desc& d, int precision) {
   return g48_lds_bytes(L) <= 160 * 1024;
 }
 
+// Workgroups (of 256 threads) of a pack launch: two output elements per thread - an element is a page of index arithmetic in
+// front of one dependent load, so the launch is latency-bound and wants threads, not a grid-stride loop (a training step packs
+// both streams of both networks every iteration: 27 + 16 us at 256 workgroups per network on the D8 / W256 nets)
+inline unsigned pack48_blocks(const NetLayout& L) {
+  const long long elems = static_cast<long long>(L.total_pieces) * 512;
+  const long long b = (elems + 511) / 512;
+  return static_cast<unsigned>(b < 64 ? 64 : (b > 4096 ? 4096 : b));
+}
+
 inline size_t g48_region_bytes(const dn_mlp_desc& d) {
   NetLayout L;
   build_layout48(d, &L);

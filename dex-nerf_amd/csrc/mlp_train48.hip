@@ -425,14 +425,14 @@ int unpack48_entry(const dn_mlp_desc* desc, int which, const void* native, int64
 int launch_pack48_backward(const dn_mlp_desc& d, const PackPtrs& ptrs, char* packed, hipStream_t stream) {
   NetLayout L;
   build_backward_layout48(d, &L);
-  hipLaunchKernelGGL(pack48_backward_kernel, dim3(512), dim3(256), 0, stream, L, ptrs, packed);
+  hipLaunchKernelGGL(pack48_backward_kernel, dim3(pack48_blocks(L)), dim3(256), 0, stream, L, ptrs, packed);
   return check_launch("mlp_pack48_backward");
 }
 
 int launch_pack48_backward_pair(const dn_mlp_desc& d, const PackPtrs& a, const PackPtrs& b, char* packed_a, char* packed_b, hipStream_t stream) {
   NetLayout L;
   build_backward_layout48(d, &L);
-  hipLaunchKernelGGL(pack48_backward_pair_kernel, dim3(256, 2), dim3(256), 0, stream, L, a, b, packed_a, packed_b);
+  hipLaunchKernelGGL(pack48_backward_pair_kernel, dim3(pack48_blocks(L), 2), dim3(256), 0, stream, L, a, b, packed_a, packed_b);
   return check_launch("mlp_pack48_backward_pair");
 }
 

@@ -33,20 +33,25 @@ for r in csv.DictReader(open(trace)):
     meta[short] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"],
                    r["Workgroup_Size_X"], r["Grid_Size_X"])
 lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
-         "Per-kernel launch durations of this repo's kernels (ns), from the kernel trace.  For the fused network",
-         "kernel the launches split into the coarse net (64 samples/ray) and the fine net (192 samples/ray);",
-         "bench.py's `roofline.kernel_ms` is the fine-net launch.", "",
+         "Per-kernel launch durations of this repo's kernels (ns), from the kernel trace.  The fused network kernel's launches are",
+         "listed per size (coarse / fine network of every configuration the command renders); bench.py's `roofline.kernel_ms` is the",
+         "fine-net launch of the headline configuration (400 x 400 rays x 192 points: the ~22-25 ms cluster of the render precision's instance).", "",
          "| kernel | calls | avg ns | min ns | max ns | VGPR | AGPR | SGPR | LDS B | scratch B | wg | grid |",
          "|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for k, v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
     m = meta[k]
     lines.append(f"| {k} | {len(v)} | {sum(v) / len(v):.0f} | {min(v)} | {max(v)} | " + " | ".join(m) + " |")
     if ("mlp_forward_kernel" in k or "mlp_forward48_kernel" in k) and len(v) > 2:
-        cut = (min(v) + max(v)) / 2
-        small = [d for d in v if d < cut]
-        big = [d for d in v if d >= cut]
-        if small and big:
-            lines.append(f"| &nbsp;&nbsp;coarse-net launches | {len(small)} | {sum(small) / len(small):.0f} | {min(small)} | {max(small)} | | | | | | | |")
-            lines.append(f"| &nbsp;&nbsp;fine-net launches | {len(big)} | {sum(big) / len(big):.0f} | {min(big)} | {max(big)} | | | | | | | |")
+        # one kernel name serves several launch sizes (coarse / fine network of each configuration the command renders): cluster
+        # the durations (a new cluster where the next duration is > 1.15x the previous one)
+        clusters, cur = [], []
+        for d in sorted(v):
+            if cur and d > 1.15 * cur[-1]:
+                clusters.append(cur); cur = []
+            cur.append(d)
+        clusters.append(cur)
+        if len(clusters) > 1:
+            for c in clusters:
+                lines.append(f"| &nbsp;&nbsp;launches of ~{sum(c) / len(c) / 1e6:.2f} ms | {len(c)} | {sum(c) / len(c):.0f} | {min(c)} | {max(c)} | | | | | | | |")
 open(os.path.join(out_dir, f"{tag}_kernel_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

@@ -259,14 +259,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
           static_assert(KXP == 2, "the xyz panel is one saved unit");
           // (the helper lambdas of the tile body are defined further down: the same store, spelled out)
           typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-          typedef short s16x2_ __attribute__((ext_vector_type(2)));
-          typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
-          auto cv = [](unsigned d0, unsigned d1) {
-            s16x2_ r = {0, 0};
-            r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, __builtin_bit_cast(bf16x2_, d0), 1.0f, false);
-            r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, __builtin_bit_cast(bf16x2_, d1), 1.0f, true);
-            return __builtin_bit_cast(unsigned, r);
-          };
+          auto cv = [](unsigned d0, unsigned d1) { return cvt_pairs_8bit<false>(d0, d1, 1.0f); };
           const u32x4_ a = __builtin_bit_cast(u32x4_, pk[0]), b = __builtin_bit_cast(u32x4_, pk[1]);
           store16_unit48(act_grp[t], static_cast<unsigned>(p.slot_xyz) * (2 * kPieceBytes), static_cast<unsigned>(ln) * 16u,
                              make_uint4(cv(a[0], a[1]), cv(a[2], a[3]), cv(b[0], b[1]), cv(b[2], b[3])));
@@ -283,14 +276,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       for (int t = 0; t < PT; ++t) { maskw[t][0] = 0u; maskw[t][1] = 0u; }
     };
     // two 16-bit pairs -> four e4m3 bytes
-    auto to_e4m3 = [](unsigned d0, unsigned d1) {
-      typedef short s16x2 __attribute__((ext_vector_type(2)));
-      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-      s16x2 r = {0, 0};
-      r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, __builtin_bit_cast(bf16x2, d0), 1.0f, false);
-      r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, __builtin_bit_cast(bf16x2, d1), 1.0f, true);
-      return __builtin_bit_cast(unsigned, r);
-    };
+    auto to_e4m3 = [](unsigned d0, unsigned d1) { return cvt_pairs_8bit<false>(d0, d1, 1.0f); };
     auto save_unit = [&](auto t_c, int slot, const BP8& lo, const BP8& hi) {
       if constexpr (SAVE != 0) {
         constexpr int t = decltype(t_c)::value;

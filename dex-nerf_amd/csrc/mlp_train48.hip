@@ -49,9 +49,12 @@ __device__ __forceinline__ void emit_grad48(const f32x4& acc, unsigned mw_lo, un
     // saturate in fp32, before the 16-bit rounding: the saved e5m2 byte is then formed straight from the 16-bit pair
     const f32x2 f = {__builtin_amdgcn_fmed3f(acc[2 * d], lo, hi), __builtin_amdgcn_fmed3f(acc[2 * d + 1], lo, hi)};
     const unsigned pair = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
-    // mask bits of registers 2d / 2d+1 sit at position p and p + 16: (bits & 0x00010001) * 0xFFFF = the AND mask of the pair
-    const unsigned keep = __umul24((word >> ((NT & 7) * 2 + d)) & 0x00010001u, 0xFFFFu);
-    w[(NT & 1) * 2 + d] = pair & keep;
+    // mask bits of registers 2d / 2d+1 sit at position p and p + 16: (bits & 0x00010001) = a 0 / 1 factor per 16-bit half, applied
+    // with ONE packed 16-bit multiply (x * 1 = x, x * 0 = 0 on the bit pattern; as a multiply by 0xFFFF and an AND it was two)
+    const unsigned bits = (word >> ((NT & 7) * 2 + d)) & 0x00010001u;
+    unsigned masked;
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(masked) : "v"(pair), "v"(bits));
+    w[(NT & 1) * 2 + d] = masked;
   }
   bo[NT / 2] = __builtin_bit_cast(bf16x8, w);
 }
@@ -151,14 +154,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
       }
     }
     // two 16-bit pairs -> four e5m2 bytes of (gradient x scale)
-    auto to_e5m2 = [&](unsigned d0, unsigned d1) {
-      typedef short s16x2 __attribute__((ext_vector_type(2)));
-      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-      s16x2 r = {0, 0};
-      r = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(r, __builtin_bit_cast(bf16x2, d0), inv_scale, false);
-      r = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(r, __builtin_bit_cast(bf16x2, d1), inv_scale, true);
-      return __builtin_bit_cast(unsigned, r);
-    };
+    auto to_e5m2 = [&](unsigned d0, unsigned d1) { return cvt_pairs_8bit<true>(d0, d1, inv_scale); };
     auto save_unit = [&](auto t_c, int slot, const BP8& lo, const BP8& hi) {
       constexpr int t = decltype(t_c)::value;
       const u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);

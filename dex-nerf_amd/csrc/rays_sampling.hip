@@ -586,6 +586,39 @@ extern "C" int dn_mse2_loss(const float* rgb_coarse, const float* rgb_fine, cons
   return check_launch("dn_mse2_loss");
 }
 
+// ---- S2 ray packing of run_one_iter_of_nerf (nerf/train_utils.py:220-250): (N,3) origins / directions -> the (N, 8 | 11) rows
+// [o, d, near, far, d_view / |d_view|] predict_and_render_radiance reads - the reference forms them with a norm, a division, two
+// ones_like, two multiplies and a cat (eight launches per image); op for op as those run on the device.
+namespace dn {
+__global__ void pack_ray_rows_kernel(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ rd_view,
+                                     float near, float far, int64_t n, float* __restrict__ rows) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float* r = rows + i * (rd_view != nullptr ? 11 : 8);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { r[j] = ro[i * 3 + j]; r[3 + j] = rd[i * 3 + j]; }
+  r[6] = near;
+  r[7] = far;
+  if (rd_view != nullptr) {
+    const float x = rd_view[i * 3], y = rd_view[i * 3 + 1], z = rd_view[i * 3 + 2];
+    // the order of torch's device reduction over three elements ((x x + z z) + y y: measured, scripts/rows_diag.py) - this kernel
+    // replaces torch ops that ran on the device, and the rows stay bit-identical to them
+    const float nrm = sqrtf((x * x + z * z) + y * y);
+    r[8] = x / nrm; r[9] = y / nrm; r[10] = z / nrm;
+  }
+}
+}  // namespace dn
+
+extern "C" int dn_pack_ray_rows(const float* rays_o, const float* rays_d, const float* view_d, float near, float far, int64_t n_rays,
+                                float* rows, dn_stream_t stream) {
+  if (n_rays == 0) return 0;
+  DN_REQUIRE(rays_o && rays_d && rows && n_rays >= 0, "dn_pack_ray_rows: bad arguments");
+  const int block = 256;
+  const unsigned grid = static_cast<unsigned>((n_rays + block - 1) / block);
+  hipLaunchKernelGGL(pack_ray_rows_kernel, dim3(grid), dim3(block), 0, as_stream(stream), rays_o, rays_d, view_d, near, far, n_rays, rows);
+  return check_launch("dn_pack_ray_rows");
+}
+
 extern "C" int dn_ndc_rays(int height, int width, double focal, double near, const float* rays_o, const float* rays_d,
                            int64_t n_rays, float* rays_o_out, float* rays_d_out, dn_stream_t stream) {
   if (n_rays == 0) return 0;

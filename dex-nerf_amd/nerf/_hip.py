@@ -28,7 +28,7 @@ EXPORTS = (
     "dn_select_rays", "dn_select_rays_indirect", "dn_ndc_rays", "dn_dex_error_sweep", "dn_depth_error_image",
     "dn_render_train_workspace_bytes", "dn_render_rays_train", "dn_render_rays_backward",
     "dn_set_s8_grad_scale", "dn_mlp_pack_parts", "dn_fp16_range_guard", "dn_select_rays_draw", "dn_mse2_loss", "dn_rng_fill", "dn_mlp_pack_train_pair",
-    "dn_adam_step",
+    "dn_adam_step", "dn_pack_ray_rows",
 )
 
 
@@ -96,6 +96,7 @@ def _declare(lib):
     lib.dn_select_rays_draw.argtypes = [c_int, c_int, fp, vp, c_int, c_float, c_float, vp, c_int64, fp, c_int, fp, fp, vp, vp]
     lib.dn_mse2_loss.argtypes = [fp, fp, fp, c_int64, c_int, fp, fp, fp, vp, vp]
     lib.dn_rng_fill.argtypes = [vp, ctypes.c_uint32, c_int64, c_int, fp, vp]
+    lib.dn_pack_ray_rows.argtypes = [fp, fp, fp, c_float, c_float, c_int64, fp, vp]
     dbl = ctypes.c_double
     lib.dn_adam_step.argtypes = [fp, fp, fp, fp, c_int64, fp, fp, dbl, dbl, dbl, dbl, dbl, c_int, vp]
     lib.dn_mlp_pack_train_pair.argtypes = [POINTER(MlpDesc), POINTER(c_void_p), POINTER(c_void_p), vp, vp, POINTER(c_void_p), POINTER(c_void_p),

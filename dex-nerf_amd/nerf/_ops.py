@@ -183,6 +183,17 @@ def rng_fill(rng_state, stream_id, shape, normal=False):
     return out
 
 
+def pack_ray_rows(ro, rd, view_d, near, far):
+    """(N,3) origins / directions -> the (N, 8 | 11) ray rows of run_one_iter_of_nerf in one launch (dn_pack_ray_rows);
+    view_d = the directions the unit view vectors come from (None: rows without them)."""
+    ro, rd = f32c(ro), f32c(rd)
+    vd = None if view_d is None else f32c(view_d)
+    n = ro.shape[0]
+    rows = torch.empty((n, 8 if vd is None else 11), dtype=torch.float32, device=ro.device)
+    check(lib().dn_pack_ray_rows(ptr(ro), ptr(rd), ptr(vd), float(near), float(far), n, ptr(rows), stream()), "dn_pack_ray_rows")
+    return rows
+
+
 def select_rays_draw(height, width, cams, view, near, far, rng_state, n_rays, images=None, want_pixels=False):
     """select_rays_indirect with the pixels drawn on the device, without replacement, from `rng_state`'s next iteration.
     view=None: the training view is drawn in the kernel too (uniformly from the cameras in `cams`)."""

@@ -1,5 +1,7 @@
 """run_network / predict_and_render_radiance / run_one_iter_of_nerf with the reference's call surface
 (reference nerf/train_utils.py:72-288), plus the Dex depth-error helpers (:9-70)."""
+import os
+
 import numpy as np
 import torch
 
@@ -264,8 +266,12 @@ def run_one_iter_of_nerf(height, width, focal_length, model_coarse, model_fine, 
     """
     _require_device(ray_directions, "run_one_iter_of_nerf")
     thres = _thresholds(m_thres_cand)
+    # device rays that need no gradient: the rows are packed by one kernel (dn_pack_ray_rows), op for op what follows
+    one_launch = (ray_directions.is_cuda and ray_origins.is_cuda and ray_directions.dtype == torch.float32
+                  and ray_origins.dtype == torch.float32 and not ray_directions.requires_grad and not ray_origins.requires_grad
+                  and os.environ.get("DEXNERF_TORCH_RAY_ROWS", "") != "1")   # (developer switch: the torch composition, for A/B timing)
     viewdirs = None
-    if options.nerf.use_viewdirs:
+    if options.nerf.use_viewdirs and not one_launch:
         viewdirs = ray_directions / ray_directions.norm(p=2, dim=-1).unsqueeze(-1)
         viewdirs = viewdirs.reshape((-1, 3))
     img_shape = ray_directions.shape
@@ -278,10 +284,14 @@ def run_one_iter_of_nerf(height, width, focal_length, model_coarse, model_fine, 
     else:
         ro, rd = ray_origins, ray_directions
     ro, rd = ro.reshape((-1, 3)), rd.reshape((-1, 3))
-    near = options.dataset.near * torch.ones_like(rd[..., :1])
-    far = options.dataset.far * torch.ones_like(rd[..., :1])
-    parts = [ro, rd, near, far] + ([viewdirs] if viewdirs is not None else [])
-    rays = torch.cat(parts, dim=-1).float()
+    if one_launch:
+        rays = _ops.pack_ray_rows(ro, rd, ray_directions.reshape((-1, 3)) if options.nerf.use_viewdirs else None,
+                                  options.dataset.near, options.dataset.far)
+    else:
+        near = options.dataset.near * torch.ones_like(rd[..., :1])
+        far = options.dataset.far * torch.ones_like(rd[..., :1])
+        parts = [ro, rd, near, far] + ([viewdirs] if viewdirs is not None else [])
+        rays = torch.cat(parts, dim=-1).float()
     chunks = [predict_and_render_radiance(batch, model_coarse, model_fine, options, mode=mode,
                                           encode_position_fn=encode_position_fn,
                                           encode_direction_fn=encode_direction_fn, m_thres_cand=thres)

@@ -1577,6 +1577,26 @@ def test_as_shipped_render_instance_with_overlapped_encoding_is_bit_identical(de
         nerf.set_precision("fp32")
 
 
+def test_ray_rows_packed_by_one_kernel_equal_the_torch_composition(dev):
+    """dn_pack_ray_rows (what run_one_iter_of_nerf uses for device rays) against the reference's composition - norm, divide,
+    ones_like x2, cat (nerf/train_utils.py:220-250) - bit for bit, with and without view directions, and through the NDC branch
+    (view directions from the unwarped rays)."""
+    import nerf
+    from nerf import _ops
+    g = torch.Generator(device=dev).manual_seed(4)
+    n = 5000
+    ro = torch.randn(n, 3, device=dev, generator=g)
+    rd = torch.randn(n, 3, device=dev, generator=g) * 3.0
+    near, far = 0.3, 4.0
+    viewdirs = rd / rd.norm(p=2, dim=-1).unsqueeze(-1)
+    expect = torch.cat([ro, rd, near * torch.ones_like(rd[..., :1]), far * torch.ones_like(rd[..., :1]), viewdirs], dim=-1).float()
+    assert torch.equal(_ops.pack_ray_rows(ro, rd, rd, near, far), expect)
+    assert torch.equal(_ops.pack_ray_rows(ro, rd, None, near, far), expect[:, :8].contiguous())
+    other = torch.randn(n, 3, device=dev, generator=g)
+    v2 = other / other.norm(p=2, dim=-1).unsqueeze(-1)
+    assert torch.equal(_ops.pack_ray_rows(ro, rd, other, near, far)[:, 8:], v2)
+
+
 def test_flat_adam_against_torch_adam(dev):
     """nerf.FlatAdam (dn_adam_step: one launch over flat parameter / gradient / moment buffers, the step count and the reference's
     learning-rate schedule inside the kernel) against torch.optim.Adam in float64 on the same gradients for 25 steps

@@ -70,6 +70,8 @@ def test_argument_validation_needs_no_gpu(hiplib):
     assert hiplib.dn_select_rays_draw(4, 4, null, null, 0, 2.0, 6.0, null, 4, null, 0, null, null, null, null) == -1000
     assert hiplib.dn_mse2_loss(null, null, null, 4, 0, null, null, null, null, null) == -1000
     assert hiplib.dn_rng_fill(null, 0, 4, 0, null, null) == -1000 and hiplib.dn_rng_fill(null, 0, 0, 0, null, null) == 0
+    assert hiplib.dn_pack_ray_rows(null, null, null, 2.0, 6.0, 4, null, null) == -1000 and hiplib.dn_pack_ray_rows(null, null, null, 2.0, 6.0, 0, null, null) == 0
+    assert hiplib.dn_adam_step(null, null, null, null, 4, null, null, 1e-3, 1.0, 0.9, 0.999, 1e-8, 0, null) == -1000
     # 8-bit saved tensors (DN_PREC_BF16_S8): the same tiles at one 1 KiB unit per PAIR of bf16 pieces; bf16 arithmetic only
     d.hidden_size = 256
     sizes = {}

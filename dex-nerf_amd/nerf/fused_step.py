@@ -123,19 +123,22 @@ class GraphedTrainStep:
         from .parallel import world_info
         world = world_info()[1]
         torch.cuda.synchronize()
+        # thread-local capture mode: with a process group alive, torch.distributed's watchdog thread queries events while this
+        # thread captures - under the default (global) mode that is a capture error
+        mode = dict(capture_error_mode="thread_local")
         if world == 1:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **mode):
                 self.fused.forward_and_fine_backward()
                 self.fused.coarse_backward()
                 self.opt.step()
             return [g]
         ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
+        with torch.cuda.graph(ga, **mode):
             self.fused.forward_and_fine_backward()
-        with torch.cuda.graph(gb, pool=ga.pool()):     # (reads what graph A allocated: one memory pool, replayed in capture order)
+        with torch.cuda.graph(gb, pool=ga.pool(), **mode):     # (reads what graph A allocated: one memory pool, replayed in capture order)
             self.fused.coarse_backward()
-        with torch.cuda.graph(gc, pool=ga.pool()):
+        with torch.cuda.graph(gc, pool=ga.pool(), **mode):
             self.opt.step()
         return [ga, gb, gc]
 

@@ -70,9 +70,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const SampleTerms t = sample_terms(raw.w, nz, noise_std, z0, z1, sc == S - 1, rd_norm);
     const double f = valid ? static_cast<double>(t.one_m_alpha) : 1.0;
     const double incl = wave_scan_mul(f) * carry;
-    double excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = carry;
-    carry = __shfl(incl, 63, 64);
+    const double excl = wave_shift_up1(incl, carry);
+    carry = wave_last(incl);
     // reference: cumprod (fp64 accumulate, fp32 per element), rolled by one, [0] = 1
     const float trans = (s == 0) ? 1.0f : static_cast<float>(excl);
     const float w = valid ? t.alpha * trans : 0.0f;
@@ -89,8 +88,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     if (n_thres > 0) {
       float cmax = valid ? t.sigma : 0.0f;   // sigma >= 0 (relu) and every threshold of interest is >= 0 ... but keep it general:
       if (!valid) cmax = -__builtin_inff();
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+      cmax = wave_max(cmax);
       const float cmax_u = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cmax)));
       for (int k = 0; k < n_thres; ++k) {
         if ((found >> k) & 1ull) continue;
@@ -170,9 +168,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const SampleTerms t = sample_terms(raw.w, nz, noise_std, z0, z1, sc == S - 1, rd_norm);
     const double f = valid ? static_cast<double>(t.one_m_alpha) : 1.0;
     const double incl = wave_scan_mul(f) * carry;
-    double excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = carry;
-    carry = __shfl(incl, 63, 64);
+    const double excl = wave_shift_up1(incl, carry);
+    carry = wave_last(incl);
     const float trans = (s == 0) ? 1.0f : static_cast<float>(excl);
     const float w = valid ? t.alpha * trans : 0.0f;
     c0_[c] = sigmoidf_(raw.x); c1_[c] = sigmoidf_(raw.y); c2_[c] = sigmoidf_(raw.z);

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "dn_common.h"
+#include "composite_body.h"
 #include "dn_rng.h"
 
 namespace dn {
@@ -104,20 +105,39 @@ extern "C" int dn_render_rays(const dn_mlp_desc* desc_coarse, const void* packed
     if (e != hipSuccess) { set_error("dn_render_rays: hipMemsetAsync: %s", hipGetErrorString(e)); return -static_cast<int>(e); }
   }
   if ((rc = dn_coarse_depths(rays, ray_stride, n_rays, num_coarse, lindisp, t_rand, w.z_c, stream))) return rc;
-  if ((rc = run_network_flagged(desc_coarse, precision, packed_coarse, nullptr, nullptr, rays, ray_stride, w.z_c, n_rays,
-                                num_coarse, w.rf_c, w.status + 1, stream)))
-    return rc;
   const bool fine = num_fine > 0;
+  DN_REQUIRE(n_thres >= 0 && n_thres <= kMaxThres, "dn_render_rays: at most %d Dex thresholds", kMaxThres);
+  // Without density noise the network launch may composite its own rays (the 48-point fixed-shape instances, samples per ray
+  // dividing their 384-point tile: the raw radiance field then never goes to HBM); it says whether it did.
+  auto comp_for = [&](float* rgb, float* acc, float* weights, float* depth, float* dex, int k) {
+    CompParams c{};
+    c.rgb = rgb; c.acc = acc; c.weights = weights; c.depth = depth; c.dex = dex; c.disp = nullptr;
+    c.nonfinite = w.status; c.n_rays = n_rays; c.n_thres = k; c.white = white_background;
+    for (int i = 0; i < kMaxThres; ++i) c.th.m[i] = (i < k) ? h_m_thres[i] : 0.0f;
+    return c;
+  };
+  const bool may_fuse = !(noise_std > 0.0f);
+  int done = 0;
   // Dex depths come from the fine pass (train_utils.py:199-201); coarse-only renders report the coarse ones.
-  if ((rc = volume_render_counting(w.rf_c, w.z_c, rays + 3, ray_stride, noise_c, noise_std, white_background, h_m_thres,
-                                   fine ? 0 : n_thres, n_rays, num_coarse, rgb_c, nullptr, acc_c, w.w_c, depth_c,
-                                   fine ? nullptr : dex_f, w.status, stream)))
+  {
+    const CompParams c = comp_for(rgb_c, acc_c, w.w_c, depth_c, fine ? nullptr : dex_f, fine ? 0 : n_thres);
+    if ((rc = run_network_flagged(desc_coarse, precision, packed_coarse, nullptr, nullptr, rays, ray_stride, w.z_c, n_rays,
+                                  num_coarse, w.rf_c, w.status + 1, stream, (may_fuse && rgb_c) ? &c : nullptr, &done)))
+      return rc;
+  }
+  if (!done && (rc = volume_render_counting(w.rf_c, w.z_c, rays + 3, ray_stride, noise_c, noise_std, white_background, h_m_thres,
+                                            fine ? 0 : n_thres, n_rays, num_coarse, rgb_c, nullptr, acc_c, w.w_c, depth_c,
+                                            fine ? nullptr : dex_f, w.status, stream)))
     return rc;
   if (!fine) return 0;
   if ((rc = dn_fine_depths(w.z_c, w.w_c, u, n_rays, num_coarse, num_fine, w.z_f, nullptr, stream))) return rc;
-  if ((rc = run_network_flagged(desc_fine, precision, packed_fine, nullptr, nullptr, rays, ray_stride, w.z_f, n_rays,
-                                num_coarse + num_fine, w.rf_f, w.status + 1, stream)))
-    return rc;
+  {
+    const CompParams c = comp_for(rgb_f, acc_f, nullptr, depth_f, dex_f, n_thres);
+    if ((rc = run_network_flagged(desc_fine, precision, packed_fine, nullptr, nullptr, rays, ray_stride, w.z_f, n_rays,
+                                  num_coarse + num_fine, w.rf_f, w.status + 1, stream, (may_fuse && rgb_f) ? &c : nullptr, &done)))
+      return rc;
+  }
+  if (done) return 0;
   return volume_render_counting(w.rf_f, w.z_f, rays + 3, ray_stride, noise_f, noise_std, white_background, h_m_thres, n_thres,
                                 n_rays, num_coarse + num_fine, rgb_f, nullptr, acc_f, nullptr, depth_f, dex_f, w.status, stream);
 }

@@ -486,7 +486,7 @@ static int launch_forward(FwdParams p, hipStream_t stream) {
   return check_launch("mlp_forward");
 }
 
-int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStream_t stream) {
+int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStream_t stream, const CompParams* comp, int* composited) {
   const bool bf = precision == DN_PREC_BF16;
   const bool hf = precision == DN_PREC_F16;
   // bf16 geometry: PT=1 (8 waves x 32 points, two waves per SIMD) measured fastest (1327 vs 1277 TFLOP/s for
@@ -497,7 +497,7 @@ int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStrea
   const char* geom_env = getenv("DEXNERF_BF16_GEOM");   // read per call: tests and probes switch it within one process
   const bool geom48 = !(geom_env && atoi(geom_env) == 32);
   if ((bf || hf) && geom48 && bf16_pt == 1 && p.act == nullptr && p.mode != 2 && p.n_points < (1LL << 31) - 1024 && g48_supported(d, precision))
-    return launch_forward48(d, precision, p, p.packed + p.bias_bytes + static_cast<size_t>(p.total_pieces) * kPieceBytes, stream);
+    return launch_forward48(d, precision, p, p.packed + p.bias_bytes + static_cast<size_t>(p.total_pieces) * kPieceBytes, stream, comp, composited);
   if (p.act != nullptr && hf) { set_error("mlp_forward(train): fp16 is a render-only mode"); return DN_E_UNSUPPORTED; }
   if (p.act != nullptr && p.save8) {   // training forward with 8-bit saved units: the 48-point geometry (mlp_fused48.hip, SAVE = 2)
     if (!bf || p.mode == 2 || !g48_train_supported(d) || p.n_points >= (1LL << 31) - 1024) {
@@ -618,7 +618,9 @@ extern "C" int dn_run_network(const dn_mlp_desc* desc, int precision, const void
 // dn_run_network + the fp16 range flag of the 48-point kernel (FwdParams::range_flag; ignored by every other kernel)
 int dn::run_network_flagged(const dn_mlp_desc* desc, int precision, const void* packed, const float* pts,
                             const float* viewdirs, const float* rays, int ray_stride, const float* z_vals,
-                            int64_t n_rays, int samples_per_ray, float* out, unsigned* range_flag, dn_stream_t stream) {
+                            int64_t n_rays, int samples_per_ray, float* out, unsigned* range_flag, dn_stream_t stream,
+                            const CompParams* comp, int* composited) {
+  if (composited) *composited = 0;
   FwdParams p;
   int rc = setup_params(desc, precision, packed, &p);
   if (rc) return rc;
@@ -638,7 +640,7 @@ int dn::run_network_flagged(const dn_mlp_desc* desc, int precision, const void* 
   p.out = out;
   p.range_flag = range_flag;
   if (p.n_points == 0) return 0;
-  return dispatch_forward(*desc, precision, p, as_stream(stream));
+  return dispatch_forward(*desc, precision, p, as_stream(stream), comp, composited);
 }
 
 extern "C" int dn_mlp_forward_encoded(const dn_mlp_desc* desc, int precision, const void* packed, const float* x,

@@ -48,9 +48,13 @@ __device__ __forceinline__ void rotate3(const float (&x)[3], int g, float (&xr)[
 // tile t + 1 during which the matrix pipes idle (18 % of this instance's pass: profiles/r02_config_sweep.md).  This instance has
 // the registers for it (the W = 256 one does not: 13 carried VGPRs + the encoding table held in 38): the rotated coordinates of
 // the next tile's points are read from the input rows after layer1, the pieces are parked in the (by then dead) LDS stash.
-template <int W, int F, int DC = 0, unsigned MASKC = 0, int VIEWC = 0, int SAVE = 0, int OVLP = 0>
+// COMP = 1 (fixed-shape render instances, samples per ray dividing the 384-point tile): the kernel composites the rays of a tile
+// itself - the raw (rgb, sigma) rows are staged in LDS instead of being written to HBM (16 B per point), and after a workgroup
+// barrier one wave per finished ray runs the body of composite_fwd_kernel on them (composite_body.h: the same code, the same bits).
+template <int W, int F, int DC = 0, unsigned MASKC = 0, int VIEWC = 0, int SAVE = 0, int OVLP = 0, int COMP = 0>
 __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdParams p, G48Params q) {
   static_assert(SAVE == 0 || (SAVE == 2 && F == 1), "saved tensors: the 8-bit layout, bf16 arithmetic");
+  static_assert(COMP == 0 || (SAVE == 0 && OVLP == 0 && DC > 0), "in-kernel compositing: a render instance whose xyz stash is free at the end of a pass");
   constexpr bool OVL = OVLP != 0;
   static_assert(!OVL || (DC >= 3 && MASKC == 0u && VIEWC != 0 && SAVE == 0 && W == 128),
                 "overlapped encoding: fixed shape, no skip layer (the stash is dead after layer1), two trunk stages of 24 output tiles");
@@ -558,13 +562,42 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     pipe.pass_end();
 #endif
     const int lo = fresh_lane();
+    if constexpr (COMP != 0) {
+      // the tile's 384 raw rows go into the xyz stash (dead from the trunk to the next tile's top; one 6 KiB image, point order)
+      f32x4* stage = reinterpret_cast<f32x4*>(smem + kRingBytes + q.bias_bytes + kG48TableBytes);
 #pragma unroll
-    for (int t = 0; t < PT; ++t) {
-      const int pt = tile * PPG + wave * PPW + t * 16 + (lo & 15);
-      if (pt < n_points && lo < 16) {
-        f32x4 o;
-        o[0] = out4[t][0]; o[1] = out4[t][1]; o[2] = out4[t][2]; o[3] = out4[t][3];
-        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p.out + static_cast<long long>(pt) * 4));
+      for (int t = 0; t < PT; ++t) {
+        if (lo < 16) {
+          f32x4 o;
+          o[0] = out4[t][0]; o[1] = out4[t][1]; o[2] = out4[t][2]; o[3] = out4[t][3];
+          stage[wave * PPW + t * 16 + lo] = o;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (not __syncthreads: its vmcnt(0) would drain the weight ring)
+      __builtin_amdgcn_s_barrier();
+      const int S = p.S;
+      const int rays_per_tile = PPG / S;
+      for (int r = wave; r < rays_per_tile; r += WAVES) {   // wave-uniform
+        const long long ray = static_cast<long long>(tile) * rays_per_tile + r;
+        if (ray < q.comp.n_rays) {
+          const f32x4* rows = stage + r * S;
+          composite_ray([&](int sc) { const f32x4 r = rows[sc]; return make_float4(r[0], r[1], r[2], r[3]); }, p.z + ray * S,
+                        p.rays + ray * p.ray_stride + 3, ray, lo, static_cast<const float*>(nullptr), 0.0f, q.comp.white, q.comp.th,
+                        q.comp.n_thres, q.comp.n_rays, S, q.comp.rgb, q.comp.disp, q.comp.acc, q.comp.weights, q.comp.depth, q.comp.dex,
+                        q.comp.nonfinite, RngRef{nullptr, 0u});
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stash is the next tile's encodings' again
+      __builtin_amdgcn_s_barrier();
+    } else {
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        const int pt = tile * PPG + wave * PPW + t * 16 + (lo & 15);
+        if (pt < n_points && lo < 16) {
+          f32x4 o;
+          o[0] = out4[t][0]; o[1] = out4[t][1]; o[2] = out4[t][2]; o[3] = out4[t][3];
+          __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p.out + static_cast<long long>(pt) * 4));
+        }
       }
     }
   }
@@ -714,7 +747,19 @@ int launch_pack48_pair(const dn_mlp_desc& d, const PackPtrs& a, const PackPtrs& 
   return check_launch("mlp_pack48_pair");
 }
 
-int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in, const char* region, hipStream_t stream) {
+// In-kernel compositing is OFF unless DEXNERF_FUSED_COMPOSITE=1 (read per call).  It is bit-identical to the two-kernel path and
+// takes the raw radiance field out of HBM (fine launch of the headline configuration: see DESIGN.md section 4.7f for the PMC bytes),
+// but it costs time: a ray is composited by ONE wave with its SIMD to itself - exponentials, divisions and an fp64 scan as one
+// dependency chain - where the standalone kernel hides that latency behind eight waves per SIMD; measured +3 % on a D8/W256
+// render and +26 % on the as-shipped 4 x 128 nets.  The network kernels are not byte-bound, so the bytes saved buy nothing back.
+static bool fused_composite_enabled() {
+  const char* e = std::getenv("DEXNERF_FUSED_COMPOSITE");
+  return e != nullptr && std::atoi(e) == 1;
+}
+
+int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in, const char* region, hipStream_t stream,
+                     const CompParams* comp, int* composited) {
+  if (composited) *composited = 0;
   NetLayout L;
   build_layout48(d, &L);
   FwdParams p = p_in;
@@ -776,6 +821,15 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
     if (paper && fixed_ok) return launch(mlp_forward48_kernel<256, 1, 8, 0x10u, 1, 2>);
     if (shipped && fixed_ok) return launch(mlp_forward48_kernel<128, 1, 4, 0u, 1, 2>);
     return d.hidden_size == 256 ? launch(mlp_forward48_kernel<256, 1, 0, 0u, 0, 2>) : launch(mlp_forward48_kernel<128, 1, 0, 0u, 0, 2>);
+  }
+  // a render that asked for its rays to be composited by the launch itself (dn_render_rays): the fixed-shape instances, whole rays
+  // per 384-point tile
+  if (comp != nullptr && comp->rgb != nullptr && (paper || shipped) && fixed_ok && p.mode == 0 && p.act == nullptr && p.S >= 1 &&
+      kG48PointsPerWg % p.S == 0 && comp->n_rays * p.S == p.n_points && fused_composite_enabled()) {
+    q.comp = *comp;
+    if (composited) *composited = 1;
+    if (precision == DN_PREC_F16) return paper ? launch(mlp_forward48_kernel<256, 2, 8, 0x10u, 1, 0, 0, 1>) : launch(mlp_forward48_kernel<128, 2, 4, 0u, 1, 0, 0, 1>);
+    return paper ? launch(mlp_forward48_kernel<256, 1, 8, 0x10u, 1, 0, 0, 1>) : launch(mlp_forward48_kernel<128, 1, 4, 0u, 1, 0, 0, 1>);
   }
   // the as-shipped nets on rays + depths (the render path): the instance that encodes tile t + 1 inside tile t (a third set of
   // view-direction rows in LDS)

@@ -6,6 +6,7 @@
 // bytes per FLOP (profiles/r01_pmc_ablations.md: +16 % on the trunk at equal matrix-pipe utilisation).
 #pragma once
 #include "mlp_internal.h"
+#include "composite_body.h"
 
 namespace dn {
 
@@ -47,6 +48,7 @@ struct G48Params {
   const char* base;  // start of the 48-point region of the packed buffer
   int bias_bytes;    // bias rows (padded to 1 KiB); the tables follow, then the pieces
   int total_pieces;
+  CompParams comp;   // the instances that composite their own rays (COMP): where the maps go; otherwise unread
 #ifdef DN_STAMP
   unsigned* dbg;     // diagnostic build: 8 words per wave
 #endif
@@ -231,7 +233,11 @@ inline int build_backward_layout48(const dn_mlp_desc& d, NetLayout* out) {
 }
 
 int launch_pack48(const dn_mlp_desc& d, int precision, const PackPtrs& ptrs, char* region, hipStream_t stream);
-int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p, const char* region, hipStream_t stream);
+// comp != NULL: the caller would like the launch to composite its rays itself (rays + depths input, no density noise); *composited
+// says whether it did (the fixed-shape instances, samples per ray dividing the 384-point workgroup tile) - if not, `out` holds the
+// raw radiance field as always and the caller runs the compositing kernel
+int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p, const char* region, hipStream_t stream,
+                     const CompParams* comp = nullptr, int* composited = nullptr);
 int backward48_entry(const dn_mlp_desc* desc, const void* packed_bwd, const float* g_out, const void* masks, int64_t n_points,
                      void* grads, float grad_scale, hipStream_t stream);                                  // mlp_train48.hip
 int unpack48_entry(const dn_mlp_desc* desc, int which, const void* native, int64_t n_points, int slot, int width, int kind, float* out,

@@ -10,7 +10,8 @@ struct PackPtrs {
 };
 
 int setup_params(const dn_mlp_desc* desc, int precision, const void* packed, FwdParams* p);
-int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStream_t stream);
+struct CompParams;
+int dispatch_forward(const dn_mlp_desc& d, int precision, FwdParams& p, hipStream_t stream, const CompParams* comp = nullptr, int* composited = nullptr);
 int launch_pack(const NetLayout& L, const PackPtrs& ptrs, void* packed, int precision, hipStream_t stream);
 
 }  // namespace dn

@@ -1597,6 +1597,44 @@ def test_ray_rows_packed_by_one_kernel_equal_the_torch_composition(dev):
     assert torch.equal(_ops.pack_ray_rows(ro, rd, other, near, far)[:, 8:], v2)
 
 
+def test_in_kernel_compositing_is_bit_identical_to_the_two_kernel_render(dev):
+    """DEXNERF_FUSED_COMPOSITE=1: the fixed-shape 48-point instances composite the rays of a tile themselves (raw rows staged in LDS,
+    one wave per finished ray runs composite_body.h - the body composite_fwd_kernel runs) instead of writing the radiance field to
+    HBM.  Off by default (it is slower: DESIGN 4.7f); where it applies every map must equal the two-kernel render bit for bit -
+    both widths, fp16 and bf16, whole rays per 384-point tile (64, 128, 192 samples; 32: twelve rays per tile, more than waves),
+    a sample count that does not divide the tile (falls back), ragged ray counts, white background, coarse-only."""
+    import nerf
+    from nerf import _hip, _ops, synthetic as syn
+    thres = [float(m) for m in range(5, 105, 5)]
+    nerf.set_precision("bf16")
+    try:
+        for width, layers, biases in ((256, 8, (-150.0, -20.0)), (128, 4, (-15.0, -2.0))):
+            kw = dict(num_layers=layers, hidden_size=width, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+            nets = []
+            for seed, b in zip((42, 43), biases):
+                m = nerf.models.FlexibleNeRFModel(**kw)
+                m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(seed, sigma_bias=b, **kw).items()})
+                nets.append(m.to(dev))
+            for prec in (_hip.PREC_F16, _hip.PREC_BF16):
+                pc, pf = nets[0].packed(precision=prec), nets[1].packed(precision=prec)
+                for n, nc, nf, white in ((1, 64, 128, False), (777, 64, 128, True), (3000, 64, 64, False), (500, 64, 192, False), (300, 32, 0, False)):
+                    g = torch.Generator(device=dev).manual_seed(n + nc)
+                    rd = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, -1.0], device=dev) + 0.3 * torch.randn(n, 3, device=dev, generator=g), dim=-1) * 1.3
+                    ro = torch.tensor([0.0, 0.0, 4.0], device=dev) + 0.05 * torch.randn(n, 3, device=dev, generator=g)
+                    rays = torch.cat([ro, rd, torch.full((n, 1), 2.0, device=dev), torch.full((n, 1), 6.0, device=dev),
+                                      torch.nn.functional.normalize(rd, dim=-1)], -1).contiguous()
+                    plain = _ops.render_rays(pc, pf if nf else None, rays, nc, nf, False, 0.0, white, thres)
+                    os.environ["DEXNERF_FUSED_COMPOSITE"] = "1"
+                    try:
+                        fused = _ops.render_rays(pc, pf if nf else None, rays, nc, nf, False, 0.0, white, thres)
+                    finally:
+                        os.environ.pop("DEXNERF_FUSED_COMPOSITE", None)
+                    for a, b in zip(fused, plain):
+                        assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), (width, prec, n, nc, nf)
+    finally:
+        nerf.set_precision("fp32")
+
+
 def test_flat_adam_against_torch_adam(dev):
     """nerf.FlatAdam (dn_adam_step: one launch over flat parameter / gradient / moment buffers, the step count and the reference's
     learning-rate schedule inside the kernel) against torch.optim.Adam in float64 on the same gradients for 25 steps

@@ -200,6 +200,10 @@ extern "C" int dn_render_rays_backward(const dn_mlp_desc* desc_coarse, const voi
   DN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "dn_render_rays_backward: workspace must be 256-byte aligned");
   Workspace w = carve(workspace, n_rays, num_coarse, num_fine, true);
   int rc;
+  // both networks, one architecture: the two backward-data chains first, then ONE weight-gradient launch for the layers of both
+  // (dn_mlp_weight_grad_pair) - a caller that wants the fine half finished early (its all-reduce under the coarse half) asks for
+  // the networks one at a time
+  const bool pair_wgrad = nets == 3 && num_fine > 0 && desc_coarse && desc_fine && std::memcmp(desc_coarse, desc_fine, sizeof(dn_mlp_desc)) == 0;
   auto half = [&](const dn_mlp_desc* desc, const void* packed_bwd, const float* rf, const float* z, int samples,
                   const float* noise, const float* g_rgb, const float* g_depth, const float* g_acc, const void* act,
                   const void* masks, void* grads, float* const* h_dW, float* const* h_db, uint32_t noise_stream) -> int {
@@ -209,6 +213,7 @@ extern "C" int dn_render_rays_backward(const dn_mlp_desc* desc_coarse, const voi
       return rc;
     const int64_t n_points = n_rays * samples;
     if ((rc = dn_mlp_backward_data(desc, precision, packed_bwd, w.g_rf, masks, n_points, grads, stream))) return rc;
+    if (pair_wgrad) return 0;   // both networks' weight gradients follow in one launch
     return dn_mlp_weight_grad_all(desc, precision, act, grads, n_points, h_dW, h_db, stream);
   };
   // the fine network first: autograd's order too (its graph node is the younger one), and the half a data-parallel caller
@@ -223,5 +228,8 @@ extern "C" int dn_render_rays_backward(const dn_mlp_desc* desc_coarse, const voi
                    masks_c, grads_c, h_dW_c, h_db_c, kRngStreamNoiseCoarse)))
       return rc;
   }
+  if (pair_wgrad)
+    return dn_mlp_weight_grad_pair(desc_fine, precision, act_f, grads_f, n_rays * (num_coarse + num_fine), h_dW_f, h_db_f, act_c, grads_c,
+                                   n_rays * num_coarse, h_dW_c, h_db_c, stream);
   return 0;
 }

@@ -1424,7 +1424,7 @@ __global__ __launch_bounds__(512, 2) void weight_grad_kernel(WgParams p) {
 // All linear layers of a network in ONE launch: the workgroups are divided among the units in proportion to the
 // bytes each unit streams, so a unit's gradient is the sum of a few dozen partials instead of one per workgroup of
 // a whole-chip launch (the fp32 atomics of the epilogue are expensive: ~1 lane-op per L2 channel per clock).
-constexpr int kWgMaxUnits = 20;
+constexpr int kWgMaxUnits = 32;   // two D <= 12 networks of one training step in one batch
 struct WgBatch {
   int n_units;
   int wg_begin[kWgMaxUnits + 1];  // unit u owns workgroups [wg_begin[u], wg_begin[u+1])
@@ -1519,61 +1519,65 @@ static int wg_attr(K kern) { return ensure_big_lds(reinterpret_cast<const void*>
 
 }  // namespace dn
 
-extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, const void* act, const void* grads,
-                                      int64_t n_points, float* const* h_dW, float* const* h_db, dn_stream_t stream) {
-  const bool s8 = precision == DN_PREC_BF16_S8;
-  if (s8) precision = DN_PREC_BF16;   // same layouts and slots, half-size pieces
-  int rc = validate_desc(desc, precision);
-  if (rc) return rc;
-  DN_REQUIRE(precision == DN_PREC_BF16 || precision == DN_PREC_F32, "dn_mlp_weight_grad_all: bf16 or fp32 buffers (fp16 is a render-only mode)");
+namespace dn {
+
+// append the (dW, db) units of ONE network to a batch; unit_tiles[u] = its 32-point tiles (networks of a batch differ in points)
+static int wg_add_network(const dn_mlp_desc* desc, int precision, bool s8, const void* act, const void* grads, int64_t n_points,
+                          float* const* h_dW, float* const* h_db, WgBatch& b, long long* unit_tiles, const char* who) {
   const bool f32 = precision == DN_PREC_F32;
-  DN_REQUIRE(act && grads && h_dW && h_db && n_points >= 0, "dn_mlp_weight_grad_all: bad arguments");
-  DN_REQUIRE(desc->num_encoding_fn_xyz == 10, "dn_mlp_weight_grad_all: training kernels are built for L_xyz = 10");
-  if (n_points == 0) return 0;
+  DN_REQUIRE(act && grads && h_dW && h_db && n_points > 0, "%s: bad arguments", who);
+  DN_REQUIRE(desc->num_encoding_fn_xyz == 10, "%s: training kernels are built for L_xyz = 10", who);
+  int rc;
   TrainLayout t;
   if (s8) {
-    DN_REQUIRE(g48_train_supported(*desc), "dn_mlp_weight_grad_all: no 8-bit-saved-tensor training kernels for this network (see dn_mlp_train_sizes)");
+    DN_REQUIRE(g48_train_supported(*desc), "%s: no 8-bit-saved-tensor training kernels for this network (see dn_mlp_train_sizes)", who);
     wg_layout_s8(*desc, &t);
   } else {
     build_train_layout(*desc, precision, &t);
   }
+  (void)f32;
   NetLayout L;
   build_layout(*desc, precision, &L);
   const int W = desc->hidden_size, D = desc->num_layers;
   const int dim_xyz = 3 + 6 * desc->num_encoding_fn_xyz, dim_dir = 3 + 6 * desc->num_encoding_fn_dir;
   const int n_units = D + (desc->use_viewdirs ? 4 : 1);
-  DN_REQUIRE(n_units <= kWgMaxUnits, "dn_mlp_weight_grad_all: too many layers (%d)", n_units);
-  for (int i = 0; i < n_units; ++i) DN_REQUIRE(h_dW[i] && h_db[i], "dn_mlp_weight_grad_all: gradient tensor %d is NULL", i);
-  WgBatch b{};
-  b.n_units = n_units;
+  const int u0 = b.n_units;
+  DN_REQUIRE(u0 + n_units <= kWgMaxUnits, "%s: too many layers (%d)", who, u0 + n_units);
+  for (int i = 0; i < n_units; ++i) DN_REQUIRE(h_dW[i] && h_db[i], "%s: gradient tensor %d is NULL", who, i);
   // parameter order: layer1, layers_xyz[0..D-2], then layers_dir.0, fc_alpha, fc_rgb, fc_feat | fc_out (models.py:207-229)
-  int u = 0;
-  if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_layer1, W, 0, 0, 1, h_dW[u], dim_xyz, h_db[u], &b.u[u], s8))) return rc;
+  int u = b.n_units;
+  if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_layer1, W, 0, 0, 1, h_dW[u - u0], dim_xyz, h_db[u - u0], &b.u[u], s8))) return rc;
   ++u;
   int x_slot = t.slot_layer1;
   for (int i = 0; i + 1 < D; ++i, ++u) {
     const bool skip = (L.skip_mask >> i) & 1u;
-    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_trunk0 + i * t.kh, W, x_slot, W, skip ? 1 : 0, h_dW[u],
-                      W + (skip ? dim_xyz : 0), h_db[u], &b.u[u], s8)))
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_trunk0 + i * t.kh, W, x_slot, W, skip ? 1 : 0, h_dW[u - u0],
+                      W + (skip ? dim_xyz : 0), h_db[u - u0], &b.u[u], s8)))
       return rc;
     x_slot = t.slot_trunk0 + i * t.kh;
   }
   if (desc->use_viewdirs) {
-    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_dirout, W / 2, t.slot_feat, W, 2, h_dW[u], W + dim_dir, h_db[u], &b.u[u], s8))) return rc;
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_dirout, W / 2, t.slot_feat, W, 2, h_dW[u - u0], W + dim_dir, h_db[u - u0], &b.u[u], s8))) return rc;
     ++u;
-    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out + 1, 1, x_slot, W, 0, h_dW[u], W, h_db[u], &b.u[u], s8))) return rc;
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out + 1, 1, x_slot, W, 0, h_dW[u - u0], W, h_db[u - u0], &b.u[u], s8))) return rc;
     ++u;
-    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out, 3, t.slot_dirout, W / 2, 0, h_dW[u], W / 2, h_db[u], &b.u[u], s8))) return rc;
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out, 3, t.slot_dirout, W / 2, 0, h_dW[u - u0], W / 2, h_db[u - u0], &b.u[u], s8))) return rc;
     ++u;
-    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_feat, W, x_slot, W, 0, h_dW[u], W, h_db[u], &b.u[u], s8))) return rc;
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_feat, W, x_slot, W, 0, h_dW[u - u0], W, h_db[u - u0], &b.u[u], s8))) return rc;
     ++u;
   } else {
-    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out, 4, x_slot, W, 0, h_dW[u], W, h_db[u], &b.u[u], s8))) return rc;
+    if ((rc = wg_fill(desc, t, act, grads, n_points, t.gslot_out, 4, x_slot, W, 0, h_dW[u - u0], W, h_db[u - u0], &b.u[u], s8))) return rc;
     ++u;
   }
-  // divide the workgroups (one per CU) among the units in proportion to the pieces each streams - the 8-bit kernel: to the cycles a
-  // tile costs, WgShape::COST - (largest remainder)
-  const long long tiles = (n_points + 31) / 32;
+  for (int i = u0; i < u0 + n_units; ++i) unit_tiles[i] = (n_points + 31) / 32;
+  b.n_units = u0 + n_units;
+  return 0;
+}
+
+// share the workgroups (one per CU) among the batch's units and launch
+static int wg_launch_batch(WgBatch& b, const long long* unit_tiles, bool f32, bool s8, dn_stream_t stream) {
+  int rc;
+  const int n_units = b.n_units;
   // (one workgroup per CU.  Two per CU on half the LDS - an instance of the W = 128 layer shapes only, 128 VGPRs - was tried for the
   // as-shipped nets, whose launches are bound by the wait / barrier / LDS round trip of a tile: the tile loop got 13-26 us shorter,
   // the reduction of twice as many partials 50 us longer - DESIGN.md section 4.6)
@@ -1581,7 +1585,8 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
   if (total_wg < n_units) total_wg = n_units;
   long long cost[kWgMaxUnits], cost_sum = 0;
   for (int i = 0; i < n_units; ++i) {
-    cost[i] = f32 ? wg_shape_pieces_f32(b.u[i].shape) : (s8 ? wg_shape_cost_s8(b.u[i].shape) : wg_shape_pieces(b.u[i].shape));
+    // (per-tile cost of the layer's shape x its tiles: the networks of one batch may differ in points)
+    cost[i] = (f32 ? wg_shape_pieces_f32(b.u[i].shape) : (s8 ? wg_shape_cost_s8(b.u[i].shape) : wg_shape_pieces(b.u[i].shape))) * unit_tiles[i];
     cost_sum += cost[i];
   }
   int share[kWgMaxUnits], given = 0;
@@ -1599,7 +1604,7 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
   }
   b.wg_begin[0] = 0;
   for (int i = 0; i < n_units; ++i) {
-    if (share[i] > tiles) share[i] = static_cast<int>(tiles);  // idle workgroups would exit at once anyway
+    if (share[i] > unit_tiles[i]) share[i] = static_cast<int>(unit_tiles[i]);  // idle workgroups would exit at once anyway
     b.wg_begin[i + 1] = b.wg_begin[i] + share[i];
   }
   if ((rc = f32 ? wg_attr(weight_grad_batch_kernel_f32) : (s8 ? wg_attr(weight_grad_batch_kernel_s8) : wg_attr(weight_grad_batch_kernel)))) return rc;
@@ -1640,6 +1645,42 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
   }
 #endif
   return check_launch("dn_mlp_weight_grad_all");
+}
+
+}  // namespace dn
+
+extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, const void* act, const void* grads,
+                                      int64_t n_points, float* const* h_dW, float* const* h_db, dn_stream_t stream) {
+  const bool s8 = precision == DN_PREC_BF16_S8;
+  if (s8) precision = DN_PREC_BF16;   // same layouts and slots, half-size pieces
+  int rc = validate_desc(desc, precision);
+  if (rc) return rc;
+  DN_REQUIRE(precision == DN_PREC_BF16 || precision == DN_PREC_F32, "dn_mlp_weight_grad_all: bf16 or fp32 buffers (fp16 is a render-only mode)");
+  DN_REQUIRE(n_points >= 0, "dn_mlp_weight_grad_all: bad arguments");
+  if (n_points == 0) return 0;
+  WgBatch b{};
+  long long unit_tiles[kWgMaxUnits];
+  if ((rc = wg_add_network(desc, precision, s8, act, grads, n_points, h_dW, h_db, b, unit_tiles, "dn_mlp_weight_grad_all"))) return rc;
+  return wg_launch_batch(b, unit_tiles, precision == DN_PREC_F32, s8, stream);
+}
+
+// The weight gradients of TWO networks of one architecture - the coarse and the fine network of a training step - in ONE launch:
+// the workgroups are shared among all their layers by cost x points, so a layer's gradient is the sum of half as many partials as
+// with two launches and the launch's fixed costs (pipeline fill, the reduction epilogue, the launch itself) are paid once.
+extern "C" int dn_mlp_weight_grad_pair(const dn_mlp_desc* desc, int precision, const void* act_a, const void* grads_a, int64_t n_points_a,
+                                       float* const* h_dW_a, float* const* h_db_a, const void* act_b, const void* grads_b,
+                                       int64_t n_points_b, float* const* h_dW_b, float* const* h_db_b, dn_stream_t stream) {
+  const bool s8 = precision == DN_PREC_BF16_S8;
+  if (s8) precision = DN_PREC_BF16;
+  int rc = validate_desc(desc, precision);
+  if (rc) return rc;
+  DN_REQUIRE(precision == DN_PREC_BF16 || precision == DN_PREC_F32, "dn_mlp_weight_grad_pair: bf16 or fp32 buffers (fp16 is a render-only mode)");
+  DN_REQUIRE(n_points_a > 0 && n_points_b > 0, "dn_mlp_weight_grad_pair: both networks need points");
+  WgBatch b{};
+  long long unit_tiles[kWgMaxUnits];
+  if ((rc = wg_add_network(desc, precision, s8, act_a, grads_a, n_points_a, h_dW_a, h_db_a, b, unit_tiles, "dn_mlp_weight_grad_pair"))) return rc;
+  if ((rc = wg_add_network(desc, precision, s8, act_b, grads_b, n_points_b, h_dW_b, h_db_b, b, unit_tiles, "dn_mlp_weight_grad_pair"))) return rc;
+  return wg_launch_batch(b, unit_tiles, precision == DN_PREC_F32, s8, stream);
 }
 
 extern "C" int dn_mlp_weight_grad(const dn_mlp_desc* desc, int precision, const void* act, const void* grads,

@@ -28,7 +28,7 @@ EXPORTS = (
     "dn_select_rays", "dn_select_rays_indirect", "dn_ndc_rays", "dn_dex_error_sweep", "dn_depth_error_image",
     "dn_render_train_workspace_bytes", "dn_render_rays_train", "dn_render_rays_backward",
     "dn_set_s8_grad_scale", "dn_mlp_pack_parts", "dn_fp16_range_guard", "dn_select_rays_draw", "dn_mse2_loss", "dn_rng_fill", "dn_mlp_pack_train_pair",
-    "dn_adam_step", "dn_pack_ray_rows",
+    "dn_adam_step", "dn_pack_ray_rows", "dn_mlp_weight_grad_pair",
 )
 
 
@@ -83,6 +83,8 @@ def _declare(lib):
     lib.dn_dex_error_sweep.argtypes = [fp, fp, c_int, c_int64, vp, c_float, c_float, vp, vp]
     lib.dn_depth_error_image.argtypes = [fp, fp, vp, c_int, c_int, c_float, fp, vp]
     lib.dn_mlp_weight_grad_all.argtypes = [POINTER(MlpDesc), c_int, vp, vp, c_int64, POINTER(c_void_p), POINTER(c_void_p), vp]
+    lib.dn_mlp_weight_grad_pair.argtypes = [POINTER(MlpDesc), c_int, vp, vp, c_int64, POINTER(c_void_p), POINTER(c_void_p), vp, vp, c_int64,
+                                            POINTER(c_void_p), POINTER(c_void_p), vp]
     lib.dn_set_s8_grad_scale.argtypes = [c_float]
     lib.dn_fp16_range_guard.argtypes = [POINTER(MlpDesc)]
     lib.dn_render_train_workspace_bytes.argtypes = [c_int64, c_int, c_int]

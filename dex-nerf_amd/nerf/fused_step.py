@@ -11,11 +11,16 @@ No autograd graph, no ATen elementwise / reduction / RNG launches: the as-shippe
 samples) is bound by those (profiles/r03_as_shipped_kernel_summary.md).  The gradients land in a parallel.FlatGradBucket (the
 `.grad` tensors of the parameters); the caller exchanges them (world > 1) and steps its optimizer.  The explicit-draw path
 (predict_and_render_radiance under autograd, draws as tensors) stays what the parity tests drive."""
+import os
+
 import torch
 
 from . import _ops
 from ._train import train_fused_ok
 from .train_utils import _fusable
+
+
+_SPLIT_BACKWARD = os.environ.get("DEXNERF_SPLIT_BACKWARD", "") == "1"   # developer switch (A/B timing): the two networks' backward as two calls even with one rank
 
 
 class FusedTrainStep:
@@ -51,10 +56,15 @@ class FusedTrainStep:
         """One iteration up to (and excluding) the end of the gradient exchange and the optimizer step.  Returns the device tensor
         [loss, mse_coarse, mse_fine]; the parameter gradients are in the bucket (world > 1: each network's all-reduce is started the
         moment its backward is enqueued - FlatGradBucket.segment_ready - and finished by bucket.all_reduce_mean())."""
+        from .parallel import world_info
         mc, mf = self.models
         mc._grad_sink.forward_issued(); mf._grad_sink.forward_issued()
         if self.zero_in_step:
             self.bucket.zero()
+        if world_info()[1] == 1 and not _SPLIT_BACKWARD:
+            self.forward_and_fine_backward(_zero=False, both=True)    # one rank: nothing to overlap, one weight-gradient launch for both networks
+            mf._grad_sink.backward_done(); mc._grad_sink.backward_done()
+            return self.loss3
         self.forward_and_fine_backward(_zero=False)
         mf._grad_sink.backward_done()     # (world > 1: the fine network's all-reduce starts here, under the coarse half)
         self.coarse_backward()
@@ -63,7 +73,9 @@ class FusedTrainStep:
 
     # The two halves a data-parallel loop replays as separate HIP graphs around the fine network's exchange (GraphedTrainStep): only
     # this library's launches and one memset - no bucket bookkeeping, no collective.
-    def forward_and_fine_backward(self, _zero=True):
+    def forward_and_fine_backward(self, _zero=True, both=False):
+        """both=True: the coarse network's backward too, in the same call - dn_render_rays_backward then forms the weight gradients
+        of both networks in ONE launch (dn_mlp_weight_grad_pair); coarse_backward() must not follow."""
         mc, mf = self.models
         sel = self.selector
         rays, target = _ops.select_rays_draw(sel.height, sel.width, sel.cams, None if self.draw_view else sel.view, sel.near, sel.far,
@@ -78,7 +90,10 @@ class FusedTrainStep:
         if views_c is None or views_f is None:
             raise RuntimeError("FusedTrainStep: a parameter's .grad is no longer the FlatGradBucket's view")
         none3 = (None, None, None)
-        keep = [_ops.render_rays_backward(pc, pf, saved, none3, (g_f, None, None), views_c, views_f, nets=2)]
+        if both:
+            keep = [_ops.render_rays_backward(pc, pf, saved, (g_c, None, None), (g_f, None, None), views_c, views_f, nets=3)]
+        else:
+            keep = [_ops.render_rays_backward(pc, pf, saved, none3, (g_f, None, None), views_c, views_f, nets=2)]
         self._half = (pc, pf, saved, g_c, views_c, views_f)
         self._keep = (keep, saved, maps, rays, target, g_c, g_f)   # alive until the next call (stream-ordered allocator)
 
@@ -129,8 +144,9 @@ class GraphedTrainStep:
         if world == 1:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, **mode):
-                self.fused.forward_and_fine_backward()
-                self.fused.coarse_backward()
+                self.fused.forward_and_fine_backward(both=not _SPLIT_BACKWARD)
+                if _SPLIT_BACKWARD:
+                    self.fused.coarse_backward()
                 self.opt.step()
             return [g]
         ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()

@@ -41,6 +41,8 @@ def test_argument_validation_needs_no_gpu(hiplib):
     # D8/W256: bias tiles (8 + 7*8 + 9 + 4 + 1) = 78 -> 10 KiB; pieces 1184 (bf16) / 2368 (fp32) KiB
     # bf16 / fp16 nets carry a second stream for the 48-points-per-wave inference kernel: 2464 bias rows -> 10 KiB,
     # 1.5 KiB of encoding tables, 1184 pieces of 16 x 32
+    null = None
+    assert hiplib.dn_mlp_weight_grad_pair(ctypes.byref(d), _hip.PREC_BF16, null, null, 4, null, null, null, null, 4, null, null, null) == -1000
     assert hiplib.dn_mlp_packed_bytes(ctypes.byref(d), _hip.PREC_BF16) == (10 + 1184) * 1024 + (10 + 1184) * 1024 + 1536
     assert hiplib.dn_mlp_packed_bytes(ctypes.byref(d), _hip.PREC_F16) == hiplib.dn_mlp_packed_bytes(ctypes.byref(d), _hip.PREC_BF16)
     assert hiplib.dn_mlp_packed_bytes(ctypes.byref(d), _hip.PREC_F32) == 10 * 1024 + 2368 * 1024

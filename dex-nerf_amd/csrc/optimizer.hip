@@ -75,7 +75,9 @@ extern "C" int dn_adam_step(float* params, float* grads, float* exp_avg, float* 
   DN_REQUIRE((reinterpret_cast<uintptr_t>(state) & 15u) == 0, "dn_adam_step: the state record is 16-byte aligned");
   const int64_t n4 = n / 4;
   int64_t grid = (n4 + 255) / 256;
-  const int64_t cap = static_cast<int64_t>(device_cus()) * 8;
+  // (one workgroup per CU: every workgroup ends with an atomic on the SAME ticket word, and same-address atomics serialise at ~10 ns
+  // each - with 8 workgroups per CU the 1,164 tickets of two D8/W256 networks were 12 of the kernel's 18 us)
+  const int64_t cap = static_cast<int64_t>(device_cus());
   if (grid > cap) grid = cap;
   hipLaunchKernelGGL(adam_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, as_stream(stream), reinterpret_cast<float4*>(params),
                      reinterpret_cast<float4*>(grads), reinterpret_cast<float4*>(exp_avg), reinterpret_cast<float4*>(exp_avg_sq), n4, state,

@@ -147,10 +147,15 @@ bool g48_range_guard_complete(const dn_mlp_desc& d);
 // magnitude (saturated: the gradient was at or beyond 57344 / scale) and how many at its smallest (the edge of being flushed to
 // zero: below 2^-17 / scale a gradient is lost).
 constexpr int kS8BlockBytes = 256;
-enum { kS8BlockSaturated = 1, kS8BlockFloor = 2, kS8BlockSampled = 3,
+// The three statistics are kept in kS8BlockReplicas copies (word kS8BlockStats + 4 r + {0, 1, 2}; a workgroup adds to copy
+// blockIdx % replicas, the reader sums the copies): atomics on ONE address serialise at ~10 ns each - with one set of counters and
+// one atomic per wave they were 40-90 us of the D8/W256 training step.
+enum { kS8BlockSaturated = 0, kS8BlockFloor = 1, kS8BlockSampled = 2,   // offsets inside a replica
        kS8BlockScale = 4,           // bits of the scale this launch used (the weight-gradient kernel divides it out)
-       kS8BlockPartials = 8,        // auto scale: kS8BlockPartialCount partial maxima of |upstream gradient| (bits)
-       kS8BlockPartialCount = 56 };
+       kS8BlockStats = 8,           // first replica
+       kS8BlockReplicas = 8,        // words 8 .. 39
+       kS8BlockPartials = 40,       // auto scale: kS8BlockPartialCount partial maxima of |upstream gradient| (bits)
+       kS8BlockPartialCount = 24 };
 
 struct TrainLayout48 {
   int32_t kh_u;                     // units of a W-wide hidden vector

@@ -1040,10 +1040,21 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
   float out_scale = 1.0f;
   if constexpr (S::S8) {
     out_scale = 1.0f / __uint_as_float(*p.scale_word);
+    // statistics: wave totals -> LDS -> three atomics per WORKGROUP into one of the record's replicas (same-address atomics
+    // serialise: one per wave on one set of counters cost the step 40-90 us)
+    unsigned* wg_stats = reinterpret_cast<unsigned*>(smem + kWgLdsBytes - 128);
+    __syncthreads();   // every wave has left the tile loop: the tile buffers are free
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const unsigned tot = static_cast<unsigned>(wave_sum(static_cast<double>(s8_stats[k])));
-      if (lane == 0 && tot != 0u) atomicAdd(p.stats_block + kS8BlockSaturated + k, tot);
+      if (lane == 0) wg_stats[wave * 4 + k] = tot;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 3) {
+      unsigned tot = 0u;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) tot += wg_stats[w8 * 4 + lane];
+      if (tot != 0u) atomicAdd(p.stats_block + kS8BlockStats + 4 * (static_cast<int>(blockIdx.x) % kS8BlockReplicas) + lane, tot);
     }
   }
   if constexpr (S::S8) {   // (in place: the epilogue below only moves values)

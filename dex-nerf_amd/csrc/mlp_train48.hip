@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
   if (blockIdx.x == 0 && threadIdx.x == 0) p.block[kS8BlockScale] = __float_as_uint(scale);
   // (the statistics words of the record are zeroed here for the weight-gradient kernel - the next launch on the stream - which
   // counts saturated / floor-level stores while it reads the gradients anyway)
-  if (blockIdx.x == 0 && threadIdx.x < 3) p.block[kS8BlockSaturated + threadIdx.x] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x < 4 * kS8BlockReplicas) p.block[kS8BlockStats + threadIdx.x] = 0u;
   const int n_points = static_cast<int>(p.n_points);   // (launches of >= 2^31 - 1024 points are refused by the host side)
 
   auto issue_gout = [&](int tile, int slot) {

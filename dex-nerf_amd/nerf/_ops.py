@@ -116,8 +116,9 @@ def s8_grad_stats(grads=None):
     recs = [grads[-S8_RECORD_BYTES:].view(torch.int32)] if grads is not None else list(_s8_records)
     if not recs:
         return None
-    rows = torch.stack([r[:8] for r in recs]).cpu()
-    sat, floor, sampled = (int(rows[:, k].sum()) for k in (1, 2, 3))
+    rows = torch.stack([r[:40] for r in recs]).cpu()
+    # eight replicas of (saturated, floor, sampled) at words 8 + 4 r (csrc/mlp_geo48.h): a workgroup adds to one of them
+    sat, floor, sampled = (int(rows[:, 8 + k:40:4].sum()) for k in (0, 1, 2))
     scales = sorted({float(v) for v in rows[:, 4].contiguous().view(torch.float32).tolist()})
     return {"saturated": sat / max(sampled, 1), "floor": floor / max(sampled, 1), "sampled": sampled, "scale": scales}
 

@@ -6,6 +6,6 @@ for r in $(seq $R); do
   for tag in "$@"; do
     unset DEXNERF_HIP_LIB DEXNERF_BF16_GEOM
     if [ "$tag" = geom32 ]; then export DEXNERF_BF16_GEOM=32; elif [ "$tag" != base ]; then export DEXNERF_HIP_LIB=exp_libs/lib$tag.so; fi
-    echo "$tag: $(python3 scripts/quick_time.py bf16 160000 2>/dev/null | tail -1)"
+    echo "$tag: $(python3 scripts/quick_time.py ${AB_PREC:-bf16} 160000 2>/dev/null | tail -1)"
   done
 done

@@ -203,7 +203,8 @@ extern "C" int dn_render_rays_backward(const dn_mlp_desc* desc_coarse, const voi
   // both networks, one architecture: the two backward-data chains first, then ONE weight-gradient launch for the layers of both
   // (dn_mlp_weight_grad_pair) - a caller that wants the fine half finished early (its all-reduce under the coarse half) asks for
   // the networks one at a time
-  const bool pair_wgrad = nets == 3 && num_fine > 0 && desc_coarse && desc_fine && std::memcmp(desc_coarse, desc_fine, sizeof(dn_mlp_desc)) == 0;
+  const bool pair_wgrad = nets == 3 && num_fine > 0 && desc_coarse && desc_fine && std::memcmp(desc_coarse, desc_fine, sizeof(dn_mlp_desc)) == 0 &&
+                          weight_grad_pair_fits(*desc_fine);   // (both networks' layers in one batch: two D <= 12 networks)
   auto half = [&](const dn_mlp_desc* desc, const void* packed_bwd, const float* rf, const float* z, int samples,
                   const float* noise, const float* g_rgb, const float* g_depth, const float* g_acc, const void* act,
                   const void* masks, void* grads, float* const* h_dW, float* const* h_db, uint32_t noise_stream) -> int {

@@ -41,6 +41,7 @@ int volume_render_counting(const float* rf, const float* z, const float* rd, int
 
 // mlp_fused.hip: dn_run_network with the fp16 range flag (a device word the 48-point fp16 kernel bumps when a hidden activation
 // left fp16's range; NULL = not wanted)
+bool weight_grad_pair_fits(const dn_mlp_desc& d);   // mlp_train.hip: the layers of two such networks fit one weight-gradient batch
 struct CompParams;   // composite_body.h
 int run_network_flagged(const dn_mlp_desc* desc, int precision, const void* packed, const float* pts, const float* viewdirs,
                         const float* rays, int ray_stride, const float* z_vals, int64_t n_rays, int samples_per_ray, float* out,

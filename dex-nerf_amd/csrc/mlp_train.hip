@@ -1585,6 +1585,8 @@ static int wg_add_network(const dn_mlp_desc* desc, int precision, bool s8, const
   return 0;
 }
 
+bool weight_grad_pair_fits(const dn_mlp_desc& d) { return 2 * (d.num_layers + (d.use_viewdirs ? 4 : 1)) <= kWgMaxUnits; }
+
 // share the workgroups (one per CU) among the batch's units and launch
 static int wg_launch_batch(WgBatch& b, const long long* unit_tiles, bool f32, bool s8, dn_stream_t stream) {
   int rc;

@@ -1,16 +1,20 @@
-"""The training iteration of the Dex-NeRF loop (reference train_dexnerf_rgb.py:229-289: pixel draw -> ray rows -> coarse + fine
-render -> mse + mse -> backward) with nothing between the pixel draw and the optimizer but this library's kernels:
+"""The training iteration of the Dex-NeRF loop (reference train_dexnerf_rgb.py:223-289: view and pixel draw -> ray rows -> coarse +
+fine render -> mse + mse -> backward -> Adam) with nothing in it but this library's kernels - 16 launches on the as-shipped nets:
 
-    dn_select_rays_draw      pixels drawn without replacement on the device + packed ray rows + target pixels      (1 kernel)
+    dn_select_rays_draw      view + pixels drawn without replacement on the device, packed ray rows, target pixels   (1 kernel)
+    dn_mlp_pack_train_pair   both weight streams of both networks                                                     (2 kernels)
     dn_render_rays_train     coarse depths / net / composite, resampling, fine net / composite; the jitter, the resampling u and
-                             the density noise drawn inside the kernels that consume them                           (7 kernels + packs)
-    dn_mse2_loss             loss, both MSEs and the two upstream gradients                                          (1 kernel)
-    dn_render_rays_backward  composite backward, backward-data chain, weight gradients - fine network, then coarse  (6 kernels)
+                             the density noise drawn inside the kernels that consume them                             (6 kernels)
+    dn_mse2_loss             loss, both MSEs and the two upstream gradients                                            (1 kernel)
+    dn_render_rays_backward  composite backward + backward-data chain per network, then ONE weight-gradient launch for the
+                             layers of both (one rank; with several ranks the networks are done one at a time so that the
+                             fine network's all-reduce overlaps the coarse half)                                       (5 kernels)
+    dn_adam_step             nerf.FlatAdam: step, learning-rate schedule and gradient clearing                         (1 kernel)
 
-No autograd graph, no ATen elementwise / reduction / RNG launches: the as-shipped configuration (4 x 128 nets, 1024 rays, 64 + 64
-samples) is bound by those (profiles/r03_as_shipped_kernel_summary.md).  The gradients land in a parallel.FlatGradBucket (the
-`.grad` tensors of the parameters); the caller exchanges them (world > 1) and steps its optimizer.  The explicit-draw path
-(predict_and_render_radiance under autograd, draws as tensors) stays what the parity tests drive."""
+No autograd graph, no ATen elementwise / reduction / RNG launches (profiles/r03_as_shipped_kernel_summary.md).  The gradients land in
+a parallel.FlatGradBucket (the `.grad` tensors of the parameters).  GraphedTrainStep replays the iteration as HIP graphs (three
+around the exchange when world > 1).  The explicit-draw path (predict_and_render_radiance under autograd, draws as tensors) stays
+what the parity tests drive."""
 import os
 
 import torch

@@ -1635,6 +1635,37 @@ def test_in_kernel_compositing_is_bit_identical_to_the_two_kernel_render(dev):
         nerf.set_precision("fp32")
 
 
+def test_training_driver_resumes_from_its_checkpoint(dev, tmp_path):
+    """train_dexnerf.py: 90 iterations + checkpoint + 60 more from the checkpoint against 150 uninterrupted ones (fused step, flat
+    Adam, device-side draws).  Training is not bit-reproducible run to run (the weight-gradient partials are added with atomics: two
+    identical runs differ by ~2e-2 in some weight after 90 iterations), so the check is on what a resume must restore: the
+    checkpoint is in the reference's format with torch.optim.Adam's state layout; the resumed run starts at iteration 90 at the
+    checkpoint's loss level (a lost optimizer state or re-initialised weights would not) and ends where the uninterrupted run ends."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "dex-nerf_amd"))
+    import nerf
+    import train_dexnerf
+    base = ["--size", "32", "--views", "6", "--num-random-rays", "512", "--layers", "4", "--width", "128", "--validate-every", "0", "--quiet",
+            "--precision", "bf16-s8", "--lr-decay", "1"]
+    ck_a, ck_b = (os.path.join(str(tmp_path), n) for n in ("a.ckpt", "b.ckpt"))
+    try:
+        first = train_dexnerf.main(base + ["--iters", "90", "--save", ck_a])
+        resumed = train_dexnerf.main(base + ["--iters", "150", "--load-checkpoint", ck_a, "--save", ck_b])
+        full = train_dexnerf.main(base + ["--iters", "150"])
+    finally:
+        nerf.set_precision("fp32")
+    a, b = torch.load(ck_a, map_location="cpu"), torch.load(ck_b, map_location="cpu")
+    assert a["iter"] == 90 and b["iter"] == 150 and set(a) >= {"model_coarse_state_dict", "model_fine_state_dict", "optimizer_state_dict", "loss", "psnr"}
+    st = a["optimizer_state_dict"]["state"]
+    assert float(st[0]["step"]) == 90.0 and set(st[0]) == {"step", "exp_avg", "exp_avg_sq"}
+    assert float(b["optimizer_state_dict"]["state"][0]["step"]) == 150.0            # the step count went on from 90
+    assert isinstance(a["optimizer_state_dict"]["param_groups"][0]["lr"], float)
+    assert resumed["history"][0][0] == 100                                          # first logged iteration of the resumed run (90 .. 149)
+    assert abs(resumed["history"][0][2] - first["history"][-1][2]) < 3.0, (resumed["history"][0], first["history"][-1])   # dB
+    assert abs(resumed["history"][-1][2] - full["history"][-1][2]) < 2.5, (resumed["history"][-1], full["history"][-1])
+    assert resumed["history"][-1][2] > first["history"][0][2] + 5.0                  # and it kept learning
+
+
 def test_flat_adam_against_torch_adam(dev):
     """nerf.FlatAdam (dn_adam_step: one launch over flat parameter / gradient / moment buffers, the step count and the reference's
     learning-rate schedule inside the kernel) against torch.optim.Adam in float64 on the same gradients for 25 steps

@@ -279,9 +279,11 @@ def dex_agreement(out, ref, sel, dev):
             "mean_miss_m": float(miss.mean()), "entries": int(miss.size)}
 
 
-def cpu_baseline(sample_rays=16384):
+def cpu_baseline(sample_rays=16384, return_aux=False):
     """The CPU oracle (a restatement of the reference's PyTorch path, pinned to goldens captured from the
-    reference) timed on this box's host cores on a bounded sample of the same workload."""
+    reference) timed on this box's host cores on a bounded sample of the same workload.
+    return_aux (the stage-wise parity test): also the oracle's intermediates per ray - coarse / merged depths, both raw radiance
+    fields, the coarse weights, the sampler's indices - and the packed ray rows (same arithmetic, same time)."""
     from nerf import synthetic as syn
     from oracle import nerf_oracle as oc
     # the GPU box gives one-GPU jobs a 16-CPU share: more threads than that only oversubscribes
@@ -294,14 +296,28 @@ def cpu_baseline(sample_rays=16384):
     ro, rd = ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]
     cfg = oc.RenderCfg(num_coarse=NC, num_fine=NF, near=2.0, far=6.0, chunksize=4096, m_thres=M_THRES)
     mc = oc.ModelCfg(**MODEL_KW)
+    aux = None
     with torch.no_grad():
         oc.run_one_iter(ro[:512], rd[:512], sd_c, sd_f, mc, mc, cfg)  # warm-up
         t0 = time.perf_counter()
-        out = oc.run_one_iter(ro, rd, sd_c, sd_f, mc, mc, cfg)
+        if not return_aux:
+            out = oc.run_one_iter(ro, rd, sd_c, sd_f, mc, mc, cfg)
+        else:   # run_one_iter's own loop (ray chunking as train_utils.py:252-271), keeping the intermediates
+            rays = oc.pack_rays(ro, rd, cfg)
+            outs, auxs = [], []
+            for i in range(0, rays.shape[0], cfg.chunksize):
+                o, a = oc.predict_and_render(rays[i: i + cfg.chunksize], sd_c, sd_f, mc, mc, cfg, None, return_aux=True)
+                outs.append(o)
+                auxs.append(dict(z_coarse=a["z_coarse"], rf_coarse=a["rf_coarse"], w_coarse=a["vc"]["weights"], z_fine=a["z_fine"],
+                                 rf_fine=a["rf_fine"], inds=a["sp"]["inds"], z_samples=a["z_samples"]))
+            out = tuple(torch.cat(c, dim=0) for c in zip(*outs))
+            aux = {k: torch.cat([a[k] for a in auxs], dim=0) for k in auxs[0]}
+            aux["rays"] = rays
         dt = time.perf_counter() - t0
-    return dict(value=sample_rays / dt, unit="rays/s", cores=threads, kind="port",
-                sample=f"{sample_rays} rays of the same 400x400 view, 64+128 samples, D8/W256 fp32, "
-                       f"torch {torch.__version__} CPU, {threads} threads, {dt:.1f} s"), sel, out
+    cb = dict(value=sample_rays / dt, unit="rays/s", cores=threads, kind="port",
+              sample=f"{sample_rays} rays of the same 400x400 view, 64+128 samples, D8/W256 fp32, "
+                     f"torch {torch.__version__} CPU, {threads} threads, {dt:.1f} s")
+    return (cb, sel, out, aux) if return_aux else (cb, sel, out)
 
 
 def main():

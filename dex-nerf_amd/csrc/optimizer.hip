@@ -45,12 +45,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ param, f
     param[i] = p; m[i] = mm; v[i] = vv;
     if (zero_grads) grad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
-  // (no fence: the ticket only orders this workgroup's READS of the state - done, their values were used above - before the last
-  // workgroup's write of it; the next launch sees that write through the kernel boundary)
+  // acquire-release on the ticket: this workgroup's READS of the state (consumed above) are ordered before its ticket, and the
+  // last workgroup's rewrite of the state after every other workgroup's ticket - by the memory model, not only by data dependence
+  // (measured: the fence is noise next to the kernel's ~10 us)
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned* ticket = reinterpret_cast<unsigned*>(state + 1);
-    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+    if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
       state[0] = count + 1.0f;
       state[2] = static_cast<float>(lr);          // the learning rate this step used (for logs)
       prod[0] = b1p; prod[1] = b2p; prod[2] = decay * decay_per_step;

@@ -637,6 +637,13 @@ def render_rays(packed_c, packed_f, rays, num_coarse, num_fine, lindisp, noise_s
     return rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f, dex
 
 
+def render_status_words(ws=None):
+    """Device copy (no synchronisation) of the two status words of the last dn_render_rays call on this stream - see
+    render_nonfinite_count; the caller sums the copies of several chunks and reads them back once."""
+    ws = render_rays.last_workspace if ws is None else ws
+    return ws[ws.numel() - 256: ws.numel() - 248].view(torch.int32).clone()
+
+
 def render_nonfinite_count(ws=None):
     """Status block of the last dn_render_rays call on this stream (synchronises): non-finite raw radiance-field samples met
     by the compositing passes + waves of the fp16 network kernel that saw an activation leave fp16's range."""

@@ -172,10 +172,13 @@ class GraphedTrainStep:
             ga, gb, gc = self.graphs
             avg = _avg_in_collective()
             op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+            # each network's segment through its own sink (the bucket's module order is the caller's choice)
+            sinks = [m._grad_sink for m in self.fused.models]
+            assert all(s.bucket is self.bucket for s in sinks), "GraphedTrainStep: both networks' gradients live in this step's bucket"
             ga.replay()
-            w_fine = dist.all_reduce(self.bucket.segment(1), op=op, async_op=True)
+            w_fine = dist.all_reduce(self.bucket.segment(sinks[1].idx), op=op, async_op=True)
             gb.replay()
-            w_coarse = dist.all_reduce(self.bucket.segment(0), op=op, async_op=True)
+            w_coarse = dist.all_reduce(self.bucket.segment(sinks[0].idx), op=op, async_op=True)
             w_fine.wait(); w_coarse.wait()
             if not avg:
                 self.bucket.flat.div_(world_info()[1])

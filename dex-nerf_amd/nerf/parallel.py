@@ -288,5 +288,25 @@ class FlatAdam(torch.optim.Optimizer):
         for key in ("betas", "eps"):
             self.param_groups[0][key] = groups[0][key]
         self._set_step(steps)
-        if not torch.is_tensor(groups[0]["lr"]):
+        # The stored lr is the value of the SAVING run's latest step: the reference rewrites param_group['lr'] every iteration
+        # (train_dexnerf_rgb.py:284-289) and saves it (:449), i.e. it is already decayed.  With the in-kernel schedule
+        # (lr_decay_steps) dn_adam_step multiplies lr0 by decay^t itself, so lr0 stays the constructor's; without a schedule the
+        # checkpoint's value is the learning rate, as in torch.optim.Adam.
+        if not torch.is_tensor(groups[0]["lr"]) and self.lr_decay_per_step == 1.0 and not torch.is_tensor(self.param_groups[0]["lr"]):
             self.param_groups[0]["lr"] = groups[0]["lr"]
+
+    def state_dict(self):
+        """torch.optim.Adam's format with INDEPENDENT tensors: every parameter its own `step` clone and cloned moments.  The live
+        state shares one 0-dim step view among all parameters and slices of two flat buffers; saved as they are, torch.save /
+        torch.load keep that sharing and torch.optim.Adam would then advance the one step once PER PARAMETER per iteration."""
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            for key in ("step", "exp_avg", "exp_avg_sq"):
+                if torch.is_tensor(st.get(key)):
+                    st[key] = st[key].detach().clone()
+        group = sd["param_groups"][0]
+        if self.lr_decay_per_step != 1.0 and not torch.is_tensor(group["lr"]):
+            # what the reference's loop would have left in param_group['lr'] (train_dexnerf_rgb.py:284-289, :449): the decayed value
+            steps = int(float(self.step_state[0]))
+            group["lr"] = float(group["lr"]) * self.lr_decay_per_step ** max(steps - 1, 0) if steps else float(group["lr"])
+        return sd

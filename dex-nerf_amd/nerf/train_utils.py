@@ -195,12 +195,12 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mo
         pc = model_coarse.packed(lx, ld, precision=prec)
         pf = model_fine.packed(lx, ld, precision=prec) if fine else None
         maps = _ops.render_rays(pc, pf, ray_batch, nc, nf if fine else 0, lindisp, std, white, thres, draws)
-        if guarded and _ops.render_nonfinite_count() > 0:
-            import warnings
-            warnings.warn("nerf: an fp16 render produced non-finite raw radiance-field values (a hidden activation beyond fp16's "
-                          "range, 65504); this render is repeated in bf16 and every later one in this process runs in bf16 "
-                          "(nerf.set_render_policy)", RuntimeWarning, stacklevel=2)
-            _FP16_RENDER_DISABLED[0] = True
+        if guarded and _DEFERRED_GUARD[0] is not None:
+            # called from run_one_iter_of_nerf: the status words of every chunk are read ONCE per image, there (no host
+            # synchronisation per chunk); a copy, because the workspace may be reused by the next chunk
+            _DEFERRED_GUARD[0].append(_ops.render_status_words())
+        elif guarded and _ops.render_nonfinite_count() > 0:
+            _warn_fp16_range()
             pc = model_coarse.packed(lx, ld)
             pf = model_fine.packed(lx, ld) if fine else None
             maps = _ops.render_rays(pc, pf, ray_batch, nc, nf if fine else 0, lindisp, std, white, thres, draws)
@@ -257,6 +257,17 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mo
     return tuple([rgb_c, depth_c, acc_c, fine_out[0], fine_out[4], fine_out[2]] + list(fine_out[5:]))
 
 
+_DEFERRED_GUARD = [None]   # a list while run_one_iter_of_nerf collects its chunks' fp16 status words, else None
+
+
+def _warn_fp16_range():
+    import warnings
+    warnings.warn("nerf: an fp16 render produced non-finite raw radiance-field values (a hidden activation beyond fp16's "
+                  "range, 65504); this render is repeated in bf16 and every later one in this process runs in bf16 "
+                  "(nerf.set_render_policy)", RuntimeWarning, stacklevel=3)
+    _FP16_RENDER_DISABLED[0] = True
+
+
 def run_one_iter_of_nerf(height, width, focal_length, model_coarse, model_fine, ray_origins, ray_directions, options,
                          mode="train", encode_position_fn=None, encode_direction_fn=None, m_thres_cand=None):
     """Pack rays, chunk, render, concatenate (reference train_utils.py:205-288).
@@ -292,10 +303,21 @@ def run_one_iter_of_nerf(height, width, focal_length, model_coarse, model_fine, 
         far = options.dataset.far * torch.ones_like(rd[..., :1])
         parts = [ro, rd, near, far] + ([viewdirs] if viewdirs is not None else [])
         rays = torch.cat(parts, dim=-1).float()
-    chunks = [predict_and_render_radiance(batch, model_coarse, model_fine, options, mode=mode,
-                                          encode_position_fn=encode_position_fn,
-                                          encode_direction_fn=encode_direction_fn, m_thres_cand=thres)
-              for batch in get_minibatches(rays, chunksize=getattr(options.nerf, mode).chunksize)]
+    def render_chunks():
+        return [predict_and_render_radiance(batch, model_coarse, model_fine, options, mode=mode,
+                                            encode_position_fn=encode_position_fn,
+                                            encode_direction_fn=encode_direction_fn, m_thres_cand=thres)
+                for batch in get_minibatches(rays, chunksize=getattr(options.nerf, mode).chunksize)]
+    _DEFERRED_GUARD[0] = []
+    try:
+        chunks = render_chunks()
+        status = _DEFERRED_GUARD[0]
+    finally:
+        _DEFERRED_GUARD[0] = None
+    if status and int(torch.stack(status).sum().item()) > 0:
+        # some chunk's fp16 render left fp16's range: the whole call again in bf16 (one host read per image, not per chunk)
+        _warn_fp16_range()
+        chunks = render_chunks()
     if len(chunks) == 1:
         images = list(chunks[0])   # a single chunk: nothing to concatenate (cat would copy every map)
     else:

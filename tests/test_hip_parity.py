@@ -1232,28 +1232,80 @@ def test_bf16_mode_renders_in_guarded_fp16_by_default(golden, dev):
 
 def test_fp32_mode_on_16384_rays_of_the_bench_scene(dev):
     """The exact-fp32 mode at the size bench.py samples (16,384 rays of the 400x400 bench view, D8/W256, 64+128) against the CPU
-    oracle.  North_star's 1e-4 is met on all but a handful of rays: an ulp in a coarse sigma moves a resampled depth across a
-    density edge there - two fp32-level evaluations of the REFERENCE's own code differ by 6.0e-4 on 3 of these rays
-    (profiles/r02_fp32_noise_floor.md); measured here: 4 rays over 1e-4, max 8.4e-4, p99.9 1.3e-5.  Gated: at most 8 rays over
-    1e-4, p99.9 <= 2e-5 on every map, Dex-depth agreement >= 0.9999."""
+    oracle, STAGE-WISE (end-to-end index equality is not achievable once the network differs by an ulp, so every
+    stage is checked on the oracle's own inputs; reference nerf/train_utils.py:136-190):
+      A. coarse network + compositing on the oracle's coarse depths: raw field, rgb / depth / acc <= 1e-4 on EVERY ray;
+      B. resampling + merge on the oracle's coarse weights: merged depths bit-exact on every ray (sample_pdf_2 + sort, :163-173);
+      C. fine network + compositing on the oracle's merged depths: raw field, rgb / depth / acc <= 1e-4 on EVERY ray;
+      D. the Dex readout on the oracle's raw field: every (threshold, ray) entry exact; on this kernel's field >= 0.9999;
+      E. end to end: every ray over 1e-4 has at least one merged depth that differs from the oracle's - the excess is resampling
+         flips (an ulp in a coarse sigma moving a sample across a density edge), nothing else; p99.9 <= 2e-5."""
     import bench
     import nerf
+    from nerf import _ops
     models, cfg, ro, rd, ex, ed = bench.build_scene(dev, 0)
     with torch.no_grad():
         out = nerf.run_one_iter_of_nerf(bench.H, bench.W, 1.0, models[0], models[1], ro, rd, cfg, mode="validation",
                                         encode_position_fn=ex, encode_direction_fn=ed, m_thres_cand=bench.M_THRES)
-    cb, sel, ref = bench.cpu_baseline(16384)
+    cb, sel, ref, aux = bench.cpu_baseline(16384, return_aux=True)
     idx = torch.from_numpy(sel).to(dev)
-    worst = {}
+    n = len(sel)
+
+    def per_ray_err(a, b):
+        a = C(a).reshape(n, -1).astype(np.float64)
+        b = b.numpy().reshape(n, -1).astype(np.float64)
+        return np.abs(a - b).max(-1) / np.abs(b).max()
+
+    rays = aux["rays"].to(dev)
+    # (the stages below run on the ORACLE's ray rows; this library's own rows may differ from them by an ulp in the unit view vector -
+    # CPU vs device norm - which is part of the end-to-end comparison E, not of the stage checks)
+    rows_equal = bool(torch.equal(rays, _ops.pack_ray_rows(ro.reshape(-1, 3)[idx], rd.reshape(-1, 3)[idx], rd.reshape(-1, 3)[idx], 2.0, 6.0)))
+    rd_s = rays[:, 3:6].contiguous()
+    pc, pf = models[0].packed(precision=_ops._hip.PREC_F32), models[1].packed(precision=_ops._hip.PREC_F32)
+    stage = {}
+    with torch.no_grad():
+        # A: coarse pass on the oracle's depths
+        z_c = _ops.coarse_depths(rays, bench.NC, False, None)
+        assert torch.equal(z_c.cpu(), aux["z_coarse"])
+        rf_c = _ops.run_network_rays(pc, rays, aux["z_coarse"].to(dev))
+        rgb_c, _, acc_c, w_c, depth_c, _ = _ops.volume_render_fwd(rf_c, z_c, rd_s, None, 0.0, False, bench.M_THRES)
+        stage["rf_coarse"] = per_ray_err(rf_c, aux["rf_coarse"])
+        stage["rgb_coarse"] = per_ray_err(rgb_c, ref[0]); stage["depth_coarse"] = per_ray_err(depth_c, ref[1]); stage["acc_coarse"] = per_ray_err(acc_c, ref[2])
+        # B: the sampler + merge on the oracle's weights
+        z_f_inj = _ops.fine_depths(aux["z_coarse"].to(dev), aux["w_coarse"].to(dev), bench.NF, None)
+        flips_b = int((z_f_inj.cpu() != aux["z_fine"]).any(-1).sum())
+        # C: fine pass on the oracle's merged depths
+        z_f = aux["z_fine"].to(dev)
+        rf_f = _ops.run_network_rays(pf, rays, z_f)
+        rgb_f, _, acc_f, _, depth_f, dex_f = _ops.volume_render_fwd(rf_f, z_f, rd_s, None, 0.0, False, bench.M_THRES, want_weights=False)
+        stage["rf_fine"] = per_ray_err(rf_f, aux["rf_fine"])
+        stage["rgb_fine"] = per_ray_err(rgb_f, ref[3]); stage["depth_fine"] = per_ray_err(depth_f, ref[4]); stage["acc_fine"] = per_ray_err(acc_f, ref[5])
+        # D: the Dex readout given the oracle's field / this kernel's field
+        dex_given = _ops.volume_render_fwd(aux["rf_fine"].to(dev), z_f, rd_s, None, 0.0, False, bench.M_THRES, want_weights=False)[5]
+        theirs = torch.stack(list(ref[6:]))
+        dex_exact = float((dex_given.cpu() == theirs).double().mean())
+        dex_stage = float((dex_f.cpu() == theirs).double().mean())
+        # E: this library's own merged depths (the stage composition is the one-call render bit for bit)
+        z_f_own = _ops.fine_depths(z_c, w_c, bench.NF, None)
+    worst = {k: (int((v > 1e-4).sum()), float(v.max())) for k, v in stage.items()}
+    for k, (over, mx) in worst.items():
+        assert over == 0, (k, over, mx, worst)
+    assert flips_b == 0, f"sampler + merge on the oracle's weights: {flips_b} rays with a differing merged depth"
+    assert dex_exact == 1.0, dex_exact
+    assert dex_stage >= 0.9999, dex_stage
+    flipped = (z_f_own.cpu() != aux["z_fine"]).any(-1).numpy()
+    e2e = {}
     for i, nm in ((0, "rgb_coarse"), (3, "rgb_fine"), (4, "depth_fine"), (5, "acc_fine")):
-        a = C(out[i].reshape(bench.H * bench.W, -1)[idx]).astype(np.float64)
-        b = ref[i].numpy().reshape(len(sel), -1).astype(np.float64)
-        per_ray = np.abs(a - b).max(-1) / np.abs(b).max()
-        worst[nm] = (int((per_ray > 1e-4).sum()), float(np.quantile(per_ray, 0.999)), float(per_ray.max()))
-        assert worst[nm][0] <= 8 and worst[nm][1] <= 2e-5, (nm, worst[nm])
+        per_ray = per_ray_err(out[i].reshape(bench.H * bench.W, -1)[idx], ref[i])
+        over = per_ray > 1e-4
+        e2e[nm] = (int(over.sum()), float(np.quantile(per_ray, 0.999)), float(per_ray.max()))
+        assert not (over & ~flipped).any(), (nm, "a ray over 1e-4 whose merged depths equal the oracle's", e2e[nm])
+        assert e2e[nm][1] <= 2e-5, (nm, e2e[nm])
     dex = bench.dex_agreement(out, ref, sel, dev)
-    _record_measurement("fp32_16384", dict(rgb_fine_over=worst["rgb_fine"][0], rgb_fine_p999=worst["rgb_fine"][1],
-                                            rgb_fine_max=worst["rgb_fine"][2], dex_agree=dex["agree_frac"], cpu_rays_per_s=cb["value"]))
+    _record_measurement("fp32_16384", dict(stagewise_max={k: v[1] for k, v in worst.items()}, rays_with_a_flipped_depth=int(flipped.sum()), ray_rows_equal=rows_equal,
+                                            rgb_fine_over=e2e["rgb_fine"][0], rgb_fine_p999=e2e["rgb_fine"][1], rgb_fine_max=e2e["rgb_fine"][2],
+                                            dex_given_sigma_exact=dex_exact, dex_stage=dex_stage, dex_agree=dex["agree_frac"],
+                                            cpu_rays_per_s=cb["value"]))
     assert dex["agree_frac"] >= 0.9999, dex
 
 
@@ -1712,16 +1764,48 @@ def test_flat_adam_against_torch_adam(dev):
             worst = [max(worst[0], e_mine), max(worst[1], e_t32)]
             assert e_mine < max(1.5 * e_t32, 1e-6), (e_mine, e_t32)      # as close to float64 Adam as torch's fp32 kernel is
     _record_measurement("flat_adam_rel_err_vs_f64", dict(mine=worst[0], torch_fp32_fused=worst[1]))
-    # checkpoints move between the two optimizers
+    # checkpoints move between the two optimizers - through a FILE, as a resumed run gets them (torch.save / torch.load keep storage
+    # sharing: a state dict whose parameters share one step tensor would advance it once per parameter per torch step)
+    import io
     sd = opt.state_dict()
+    assert sd["param_groups"][0]["lr"] == pytest.approx(lr0 * factor ** (24 / steps_decay), rel=1e-12)   # the decayed value, as the reference saves it (train_dexnerf_rgb.py:284-289, :449)
+    buf = io.BytesIO()
+    torch.save(sd, buf)
+    buf.seek(0)
+    sd = torch.load(buf, map_location=dev)
     t_params = [p.detach().clone().requires_grad_(True) for p in bucket.params]
     t_opt = torch.optim.Adam(t_params, lr=lr0)
     t_opt.load_state_dict(sd)
     assert float(t_opt.state[t_params[0]]["step"]) == 25.0
+    for t in t_params:
+        t.grad = torch.ones_like(t)
+    t_opt.step()
+    assert all(float(t_opt.state[t]["step"]) == 26.0 for t in t_params)          # ONE step for every parameter
+    assert float(opt.step_state[0]) == 25.0                                       # and the live optimizer's state was not aliased
+    # torch.optim.Adam with a per-iteration decayed lr (the reference's loop) -> FlatAdam with the in-kernel schedule: the stored lr is
+    # already decayed and must not be decayed again
+    k = 7
+    t2_params = [p.detach().clone().requires_grad_(True) for p in bucket.params]
+    t2 = torch.optim.Adam(t2_params, lr=lr0)
+    for it in range(k):
+        for t in t2_params:
+            t.grad = torch.full_like(t, 1e-3)
+        t2.step()
+        for group in t2.param_groups:
+            group["lr"] = lr0 * factor ** (it / steps_decay)
     nets2 = [nerf.models.FlexibleNeRFModel(**mkw).to(dev) for _ in range(2)]
-    opt2 = nerf.FlatAdam(parallel.FlatGradBucket(nets2), lr=lr0)
-    opt2.load_state_dict(t_opt.state_dict())
-    assert float(opt2.step_state[0]) == 25.0 and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    b2 = parallel.FlatGradBucket(nets2)
+    opt2 = nerf.FlatAdam(b2, lr=lr0, lr_decay_factor=factor, lr_decay_steps=steps_decay)
+    opt2.load_state_dict(t2.state_dict())
+    assert float(opt2.step_state[0]) == float(k)
+    for p in b2.params:
+        p.grad.fill_(1e-3)
+    opt2.step()
+    assert opt2.last_lr() == pytest.approx(lr0 * factor ** (k / steps_decay), rel=1e-6)
+    # moments survive the torch -> flat direction
+    opt3 = nerf.FlatAdam(parallel.FlatGradBucket([nerf.models.FlexibleNeRFModel(**mkw).to(dev) for _ in range(2)]), lr=lr0)
+    opt3.load_state_dict(sd)
+    assert float(opt3.step_state[0]) == 25.0 and torch.equal(opt3.exp_avg, opt.exp_avg) and torch.equal(opt3.exp_avg_sq, opt.exp_avg_sq)
 
 
 # ---- the draws of a training iteration made on the device (csrc/dn_rng.h, nerf.FusedTrainStep) ---------------------------------

@@ -1302,7 +1302,7 @@ def test_fp32_mode_on_16384_rays_of_the_bench_scene(dev):
         assert not (over & ~flipped).any(), (nm, "a ray over 1e-4 whose merged depths equal the oracle's", e2e[nm])
         assert e2e[nm][1] <= 2e-5, (nm, e2e[nm])
     dex = bench.dex_agreement(out, ref, sel, dev)
-    _record_measurement("fp32_16384", dict(stagewise_max={k: v[1] for k, v in worst.items()}, rays_with_a_flipped_depth=int(flipped.sum()), ray_rows_equal=rows_equal,
+    _record_measurement("fp32_16384", dict(**{"stage_max_" + k: v[1] for k, v in worst.items()}, rays_with_a_flipped_depth=int(flipped.sum()), ray_rows_equal=rows_equal,
                                             rgb_fine_over=e2e["rgb_fine"][0], rgb_fine_p999=e2e["rgb_fine"][1], rgb_fine_max=e2e["rgb_fine"][2],
                                             dex_given_sigma_exact=dex_exact, dex_stage=dex_stage, dex_agree=dex["agree_frac"],
                                             cpu_rays_per_s=cb["value"]))

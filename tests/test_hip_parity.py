@@ -1804,7 +1804,7 @@ def test_flat_adam_against_torch_adam(dev):
     assert opt2.last_lr() == pytest.approx(lr0 * factor ** (k / steps_decay), rel=1e-6)
     # moments survive the torch -> flat direction
     opt3 = nerf.FlatAdam(parallel.FlatGradBucket([nerf.models.FlexibleNeRFModel(**mkw).to(dev) for _ in range(2)]), lr=lr0)
-    opt3.load_state_dict(sd)
+    opt3.load_state_dict(opt.state_dict())      # (a fresh one: torch's load_state_dict adopted `sd`'s tensors and t_opt.step() advanced them)
     assert float(opt3.step_state[0]) == 25.0 and torch.equal(opt3.exp_avg, opt.exp_avg) and torch.equal(opt3.exp_avg_sq, opt.exp_avg_sq)
 
 

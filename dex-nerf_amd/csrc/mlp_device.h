@@ -17,6 +17,7 @@
      defined(DN_WG_NOREAD) || defined(DN_WG_NOSTAGE) || defined(DN_WG_STAMP) || defined(DN_WG_EPI) || defined(DN_WG_LOAD_POLICY_ID) ||  \
      defined(DN_WG_ONLY) || defined(DN_G48_PREFETCH) || defined(DN_G48_COMPILER_READS) || defined(DN_G48_SYMMETRIC_DMA) ||               \
      defined(DN_G48_PRIO) || defined(DN_G48_BARRIER_EVERY_PHASE) || defined(DN_G48_SKIP_PE_FROM_LDS) ||                                 \
+     defined(DN_EXP_NOEPI) || defined(DN_EXP_NOWAIT) || defined(DN_EXP_NOTOP) || defined(DN_G48_EPI_PIN) || defined(DN_EXP_HALF) || defined(DN_EXP_ONLY_PAPER) || defined(DN_G48_NO_XS) ||                                                          \
      (defined(DN_PREFETCH) && !defined(DN_PREFETCH_SET_BY_KERNEL_SOURCE)))
 #error "DN_EXP_* / DN_WG_* / DN_G48_* / DN_PREFETCH / DN_STORE_POLICY_ID are ablation hooks: build them with scripts/build_exp.sh (-DDN_ABLATION_BUILD), never into libdexnerf_hip.so"
 #endif
@@ -409,8 +410,10 @@ struct DN_PIPE_CLASS {
     if (st_top_pending) { st_top += stamp() - st_last; st_top_pending = 0; ++st_n; }
 #endif
     if constexpr (EVEN) {
+#ifndef DN_EXP_NOBARRIER   // timing experiment only (UNSAFE: no cross-wave ordering of ring slots)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+#endif
       advance_issue();
       dma_phase(pend_src, pend_dst, wave < 4 ? 1u : 0u);
       dma_phase(pend_src + PER_WAVE * kPieceBytes, pend_dst + PER_WAVE * kPieceBytes, wave < 4 ? 1u : 0u);
@@ -425,6 +428,64 @@ struct DN_PIPE_CLASS {
       advance_issue();
       dma_phase(pend_src, pend_dst, wave < 4 ? 1u : 0u);
       dma_phase(pend_src + PER_WAVE * kPieceBytes, pend_dst + PER_WAVE * kPieceBytes, wave < 4 ? 1u : 0u);
+    }
+  }
+#endif
+#if defined(DN_PIPE_ASM_READS) && defined(DN_PIPE_LEADER_DMA)
+  // ---- the same two-phase period with the fetch SPREAD over the period's first half (explicit-schedule instances, run_stage48x).
+  // What a weight DMA costs its wave is the queue in front of the CU's one address path: behind the barrier the four fetching waves
+  // used to issue four 1 KiB loads each at once (and four more at mid-phase) - ~80 cycles per load for the issuing wave, measured
+  // with waves 0-3 running alone (profiles/r04_headline_schedule.md).  Here ONE wave issues at a time, two loads per piece
+  // position: wave w (0-3) at positions 4w .. 4w + 3 of the 32-piece period - pieces 4w .. 4w + 3 of phase p + 3, then of phase
+  // p + 4.  The last load leaves at position 15; the barrier that needs it landed (vmcnt(0), even phase p + 2) is 16 pieces later.
+  // Scalar state per period: this wave's global source and LDS destination of its four pieces of either phase.
+  unsigned long long xs_src[2];
+  unsigned xs_dst[2];
+  __device__ __forceinline__ void xs_period_begin() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef DN_EXP_NOBARRIER
+    __builtin_amdgcn_s_barrier();
+#endif
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      advance_issue();   // (pend_src / pend_dst: this wave's 4 KiB of the phase)
+      const unsigned long long bits = reinterpret_cast<unsigned long long>(wsrc + pend_src);
+      const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits));
+      const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits >> 32));
+      xs_src[h] = (static_cast<unsigned long long>(hi) << 32) | lo;
+      xs_dst[h] = __builtin_amdgcn_readfirstlane(ring_addr + pend_dst);
+    }
+  }
+  // position Q (0 .. 15) of the period: wave Q / 4 issues two loads (1 KiB each); everyone else skips (branch inside the statement)
+  template <int Q>
+  __device__ __forceinline__ void xs_dma_step() {
+#ifndef DN_EXP_NODMA
+    constexpr int H = (Q % 4) / 2;            // which of the two phases
+    constexpr int OFF = (Q % 2) * 2048;       // which pair of this wave's four pieces
+    unsigned keep;
+    asm volatile(
+        "s_cmp_lg_u32 %[wave], %[who]\n\t"
+        "s_cbranch_scc1 .Ldn_xs_skip%=\n\t"
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\t"
+        "s_nop 1\n\t"
+        "global_load_lds_dwordx4 %[voff], %[sbase] offset:%[o0]\n\t"
+        "global_load_lds_dwordx4 %[voff], %[sbase] offset:%[o1]\n\t"
+        "s_mov_b32 m0, %[keep]\n"
+        ".Ldn_xs_skip%=:"
+        : [keep] "=&s"(keep)
+        : [wave] "s"(wave), [who] "n"(Q / 4), [lds] "s"(xs_dst[H]), [voff] "v"(lane16), [sbase] "s"(xs_src[H]), [o0] "n"(OFF), [o1] "n"(OFF + 1024)
+        : "memory", "scc");
+#endif
+  }
+  template <int POS>
+  __device__ __forceinline__ void at_position_xs() {
+    constexpr int Q = POS % (2 * kPhasePieces);
+    if constexpr (Q == 0) xs_period_begin();
+    if constexpr (POS % kPhasePieces == 0) {
+      slot_nxt = (slot_nxt + 1 == kRingPhases) ? 0 : slot_nxt + 1;
+      rda_cur = slot_cur_base + lane16;
+      slot_cur_base = __builtin_amdgcn_readfirstlane(ring_addr + slot_nxt * kSlotBytes);
     }
   }
 #endif
@@ -470,6 +531,21 @@ struct DN_PIPE_CLASS {
 #endif
   }
 
+#if defined(DN_PIPE_ASM_READS) && defined(DN_PIPE_LEADER_DMA)
+  // the same for the explicit-schedule pass: the fetch steps of the skipped positions still happen
+  template <int POS, int N>
+  __device__ __forceinline__ void skip_xs() {
+    static_for<N>([&](auto i_c) {
+      constexpr int pos = POS + decltype(i_c)::value;
+      static_assert(pos % kPhasePieces != 0 || decltype(i_c)::value == 0, "padding never crosses a phase");
+      static_assert(pos % (2 * kPhasePieces) != 0, "padding never opens a barrier period");
+      if constexpr ((pos % (2 * kPhasePieces)) < kPhasePieces) xs_dma_step<pos % (2 * kPhasePieces)>();
+      if constexpr (decltype(i_c)::value >= N - kPrefetch) prefetch<pos>();
+    });
+    settle<true>();
+  }
+#endif
+
   // after consuming piece POS (position within the 16-piece phase), read piece POS + kPrefetch into its FIFO slot
   template <int POS>
   __device__ __forceinline__ void prefetch() {
@@ -498,7 +574,11 @@ struct DN_PIPE_CLASS {
   // piece POS is about to be consumed: wait until at most NEWER of our younger reads are outstanding
   template <int POS, int NEWER>
   __device__ __forceinline__ f32x4 take() {
+#ifdef DN_EXP_NOWAIT   // timing experiment only (UNSAFE: fragments are consumed before they have arrived)
+    asm volatile("; no wait %1" : "+v"(af[POS % kPrefetch]) : "n"(NEWER));
+#else
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[POS % kPrefetch]) : "n"(NEWER));
+#endif
     return af[POS % kPrefetch];
   }
   // bias rows of the next tile: addr = LDS byte address of this lane group's 16 bytes of a bias tile, OFF = byte offset

@@ -61,6 +61,12 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
   constexpr int VSETS = OVL ? 3 : 2;           // view-direction row sets: the inputs of tile t + 2 arrive during tile t
   constexpr int IN_ROWS = 7 + 3 * VSETS;
   constexpr bool FIXED = DC > 0;
+  // explicit-schedule tile pass (run_stage48x): the paper network's render instances
+#ifdef DN_G48_NO_XS
+  constexpr bool XS = false;
+#else
+  constexpr bool XS = FIXED && W == 256 && SAVE == 0 && OVLP == 0 && COMP == 0 && VIEWC != 0;
+#endif
   constexpr bool ST = !FIXED;   // settle at stage ends
   constexpr bool CL = SAVE != 0;   // clamp stage outputs to e4m3's range (emit48)
 #if defined(DN_PIPE_ASM_READS) && defined(DN_PIPE_LEADER_DMA) && !defined(DN_G48_BARRIER_EVERY_PHASE)
@@ -167,6 +173,9 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
   for (int ph = 0; ph < (PH == kPhasePieces ? kRingPhases - 1 : kRingPhases - 2); ++ph) pipe.issue_phase();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef DN_EXP_HALF   // timing experiment only: one wave per SIMD does the work (what a wave sustains ALONE); 1: waves 0-3, 2: waves 4-7 (+ the fetching by 0-3 is lost: combine with DN_EXP_NODMA)
+  if ((DN_EXP_HALF == 1) ? wave >= 4 : wave < 4) return;
+#endif
   pipe.slot_nxt = 0;
   // this lane group's 4 rows of bias tile 0 (LDS byte address; the stages add tile offsets)
   // (rebuilt at every use from an opaque copy of the thread index - see fresh_lane - instead of being carried in a VGPR)
@@ -222,7 +231,11 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     // ---- xyz encoding of this lane's three points, its 16 columns each, into the per-wave LDS stash ----
     // (OVL: only a workgroup's first tile is encoded here; every later one was encoded during the tile before it)
     const bool first_tile = tile == static_cast<int>(blockIdx.x);
+#ifdef DN_EXP_NOTOP   // timing experiment only: no top-of-tile block (the stash keeps whatever it held; inputs are not staged)
+    if (false) {
+#else
     if (!OVL || first_tile) {
+#endif
       const int ln = fresh_lane();
       const int j = ln & 15;
       const f32x4* tabx = reinterpret_cast<const f32x4*>(tab_lds) + (ln >> 4) * 16;
@@ -326,6 +339,104 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 
     BP8 ba[PT][KH], bb[PT][KH];
     int bias_tile = 0;
+    float out4[PT][4];
+    if constexpr (XS) {
+      // ================= explicit schedule (mlp_stage48.h run_stage48x): same stages, same pieces, same arithmetic =================
+      static_assert(PH == 2 * kPhasePieces && DC >= 2 && KDP == 1, "the two-phase barrier period; the view-direction panel is one piece");
+      static_assert((NT * KXP) % PH == 0 && (NT * KH) % PH == 0 && (NT * (KH + KXP)) % PH == 0, "every stage starts at position 0 of a barrier period");
+      f32x4 pacc[PT];
+      auto nothing = [&](auto) {};
+      // ---- layer1: xyz encoding -> W, no activation (models.py:238) ----
+      {
+        BP8 pe[PT][KXP];
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+          for (int k = 0; k < KXP; ++k) pe[t][k] = pe_xyz(t, k);
+        run_stage48x<F, NT, KXP, 0, 0, false, 0, 6, 0, 0>(pipe, pe, no_pe, bias_at(0), 0u, pacc,
+            [&](auto nt_c, auto s_c) { hidden_op48<F, false, decltype(nt_c)::value, decltype(s_c)::value>(pacc, ba); }, nothing);
+      }
+      bias_tile += NT;
+      // ---- trunk (models.py:239-246): each stage's first blocks finish the stage before it ----
+      static_for<DC - 1>([&](auto i_c) {
+        constexpr int i = decltype(i_c)::value;
+        auto& bin = (i % 2 == 0) ? ba : bb;
+        auto& bout = (i % 2 == 0) ? bb : ba;
+        auto ops = [&](auto nt_c, auto s_c) { hidden_op48<F, true, decltype(nt_c)::value, decltype(s_c)::value>(pacc, bout); };
+        auto pend = [&](auto s_c) { hidden_op48<F, (i > 0), NT - 1, decltype(s_c)::value>(pacc, bin); };
+        constexpr int PN = i > 0 ? 12 : 6;
+        constexpr int BY = (NT - 1) / 2;
+        if constexpr ((MASKC >> i) & 1u) {
+          BP8 pe[PT][KXP];   // the skip layer's second K panel, in registers for the stage (see layer1)
+#pragma unroll
+          for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int k = 0; k < KXP; ++k) pe[t][k] = pe_xyz(t, k);
+          run_stage48x<F, NT, KH, KXP, 0, false, 0, 12, PN, BY, (i == 0 ? 2 : 1)>(pipe, bin, [&](int t, int k) { return pe[t][k]; }, bias_at(bias_tile), 0u, pacc, ops, pend, &trk);
+        } else {
+          run_stage48x<F, NT, KH, 0, 0, false, 0, 12, PN, BY, (i == 0 ? 2 : 1)>(pipe, bin, no_pe, bias_at(bias_tile), 0u, pacc, ops, pend, &trk);
+        }
+        bias_tile += NT;
+      });
+      auto& hx = ((DC - 1) % 2 == 0) ? ba : bb;
+      auto& hy = ((DC - 1) % 2 == 0) ? bb : ba;
+      // ---- fc_alpha (its own 16-row tile, row 0, streamed first) + fc_feat with ReLU (models.py:248-249) ----
+      run_stage48x<F, 1, KH, 0, 0, false, 0, 3, (DC > 1 ? 12 : 6), (NT - 1) / 2>(pipe, hx, no_pe, bias_at(bias_tile), 0u, pacc,
+          [&](auto, auto s_c) { constexpr int t = decltype(s_c)::value; pick_op48(out4[t][3], pacc[t][0]); },   // row 0: lane group 0, register 0
+          [&](auto s_c) { hidden_op48<F, (DC > 1), NT - 1, decltype(s_c)::value>(pacc, hx); });
+      run_stage48x<F, NT, KH, 0, KH % PH, false, 0, 12, 3, KH, 1>(pipe, hx, no_pe, bias_at(bias_tile + 1), 0u, pacc,
+          [&](auto nt_c, auto s_c) { hidden_op48<F, true, decltype(nt_c)::value, decltype(s_c)::value>(pacc, hy); },
+          [&](auto s_c) { constexpr int t = decltype(s_c)::value; pick_op48(out4[t][3], pacc[t][0]); }, &trk);
+      bias_tile += NT + 1;
+      // ---- view-direction encoding (one 32-deep piece per point group), into the xyz stash (dead once the trunk is done) ----
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int ln = fresh_lane();
+        const int j = ln & 15;
+        const f32x4* tabd = reinterpret_cast<const f32x4*>(tab_lds + 1024) + (ln >> 4) * 8;
+        char* pex = pex_of(ln);
+        static_for<PT>([&](auto t_c) {
+          constexpr int t = decltype(t_c)::value;
+          float v[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) v[c] = inbuf[(7 + 3 * vset + c) * PPW + t * 16 + j];
+          float vr[3];
+          rotate3(v, ln >> 4, vr);
+          BP8 piece;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) piece[e] = static_cast<Elem>(pe_value(vr[e % 3], tabd[e]));
+          *reinterpret_cast<BP8*>(pex + t * kPieceBytes) = piece;
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- layers_dir[0] on cat(feat, view) -> W/2, ReLU (models.py:250-252) ----
+      constexpr int POS_D = ((NT + 1) * KH) % PH;
+      BP8 bg[PT][KH / 2];
+      BP8 ped[PT];
+#pragma unroll
+      for (int t = 0; t < PT; ++t) ped[t] = *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ped[0]), "+v"(ped[1]), "+v"(ped[2]), "+v"(pipe.af[0]), "+v"(pipe.af[1]), "+v"(pipe.bias_nxt));
+      run_stage48x<F, NT / 2, KH, KDP, POS_D, false, 0, 12, 12, (NT - 1) / 2, 1>(pipe, hy, [&](int t, int) { return ped[t]; }, bias_at(bias_tile), 0u, pacc,
+          [&](auto nt_c, auto s_c) { hidden_op48<F, true, decltype(nt_c)::value, decltype(s_c)::value>(pacc, bg); },
+          [&](auto s_c) { hidden_op48<F, true, NT - 1, decltype(s_c)::value>(pacc, hy); }, &trk);
+      bias_tile += NT / 2;
+      // ---- fc_rgb (models.py:253) ----
+      constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % PH;
+      constexpr int END = POS_R + KH / 2;
+      static_assert(END <= PH && (END - 1) / kPhasePieces == POS_R / kPhasePieces, "the tail stays inside one phase");
+      constexpr int PAD_R = (kPhasePieces - END % kPhasePieces) % kPhasePieces;
+      static_assert((END + PAD_R) % PH == 0, "a tile pass is a whole number of barrier periods");
+      run_stage48x<F, 1, KH / 2, 0, POS_R, true, PAD_R, 9, 12, (NT / 2 - 1) / 2, 1>(pipe, bg, no_pe, bias_at(bias_tile), bias_at(0), pacc,
+          [&](auto, auto s_c) { constexpr int sv = decltype(s_c)::value; pick_op48(out4[sv / 3][sv % 3], pacc[sv / 3][sv % 3]); },
+          [&](auto s_c) { hidden_op48<F, true, NT / 2 - 1, decltype(s_c)::value>(pacc, bg); }, &trk);
+      if constexpr (PAD_R != 0) pipe.template skip_xs<END, PAD_R>();   // (settles at its end)
+      else pipe.settle();
+      // the last tile's rows: nothing rides behind this stage, so its accumulators are read here - behind the wait states a 4-pass
+      // MFMA's result needs (7; the compiler sees no MFMA and pads nothing)
+      asm volatile("s_nop 7\n\ts_nop 1" ::: "memory");
+      static_for<9>([&](auto s_c) { constexpr int sv = decltype(s_c)::value; pick_op48(out4[sv / 3][sv % 3], pacc[sv / 3][sv % 3]); });
+    } else {
     // ---- layer1: xyz encoding -> W, no activation (models.py:238) ----
     // (the encoding pieces go into registers once per stage - bb is still free here: read through the pe_xyz lambda they
     // are re-read from LDS for every tile, because the DMA asm's memory clobber forbids the compiler to keep them, each time
@@ -393,7 +504,6 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         if constexpr (e == 7) *reinterpret_cast<BP8*>(pex_of(fresh_lane()) + (tq * KXP + k) * kPieceBytes) = encp;
       }
     };
-    float out4[PT][4];
     // ---- heads on the trunk output hx (hy: the other, by then free, activation set) ----
     auto heads = [&](const BP8 (&hx)[PT][KH], BP8 (&hy)[PT][KH], auto view_c) __attribute__((always_inline)) {
       if constexpr (decltype(view_c)::value) {
@@ -558,6 +668,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       if (p.use_viewdirs) heads(ba, bb, std::true_type{});
       else heads(ba, bb, std::false_type{});
     }
+    }   // !XS
 #ifdef DN_STAMP
     pipe.pass_end();
 #endif
@@ -816,6 +927,12 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
   const bool paper = d.hidden_size == 256 && d.num_layers == 8 && L.skip_mask == 0x10u && d.use_viewdirs;
   const bool shipped = d.hidden_size == 128 && d.num_layers == 4 && L.skip_mask == 0u && d.use_viewdirs;
   const bool fixed_ok = std::getenv("DEXNERF_G48_RUNTIME_SHAPE") == nullptr;
+#ifdef DN_EXP_ONLY_PAPER   // experiment builds: only the headline instances are compiled (minutes -> seconds per build)
+  if (paper && p.act == nullptr && precision == DN_PREC_F16) return launch(mlp_forward48_kernel<256, 2, 8, 0x10u, 1>);
+  if (paper && p.act == nullptr) return launch(mlp_forward48_kernel<256, 1, 8, 0x10u, 1>);
+  set_error("mlp_forward48: experiment build (DN_EXP_ONLY_PAPER)");
+  return DN_E_UNSUPPORTED;
+#else
   if (p.act != nullptr) {   // training forward (DN_PREC_BF16_S8): saved units + mask words
     if (precision != DN_PREC_BF16 || !p.save8) { set_error("mlp_forward48(train): the 48-point training forward is the bf16 / 8-bit-saved-tensor mode"); return DN_E_UNSUPPORTED; }
     if (paper && fixed_ok) return launch(mlp_forward48_kernel<256, 1, 8, 0x10u, 1, 2>);
@@ -846,6 +963,7 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
   if (paper && fixed_ok) return launch(mlp_forward48_kernel<256, 1, 8, 0x10u, 1>);
   if (shipped && fixed_ok) return launch(mlp_forward48_kernel<128, 1, 4, 0u, 1>);
   return d.hidden_size == 256 ? launch(mlp_forward48_kernel<256, 1>) : launch(mlp_forward48_kernel<128, 1>);
+#endif
 }
 
 }  // namespace dn

@@ -89,6 +89,19 @@ __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, 
       }
       const auto a = __builtin_bit_cast(typename Prec<F>::BPiece, pipe.af[pos % kPrefetch]);
 #endif
+#ifdef DN_G48_EPI_PIN
+      // the previous tile's epilogue (12 conversions / ReLUs, same scheduling region: it follows the sched_barrier below) goes ONE
+      // vector instruction per MFMA gap - an MFMA holds the SIMD's vector issue for 8 of its 16 cycles, one 4-5-cycle instruction
+      // fits the rest - after DN_G48_EPI_PIN leading MFMAs (distance to the accumulators' last writes: no hazard nops)
+      if constexpr (k == 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, DN_G48_EPI_PIN, 0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      }
+#endif
       static_for<PT>([&](auto t_c) {
         constexpr int t = decltype(t_c)::value;
         if constexpr (k < KH) acc[t] = mfma48<F>(a, bh[t][k], acc[t]);
@@ -151,6 +164,174 @@ __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, 
 #endif
 }
 
+// ===== explicit-schedule stage (the fixed-shape W = 256 render instances) ==========================================================
+// Measured on the round-3 kernel (profiles/r04_headline_schedule.md): ONE wave of a SIMD running the tile pass alone keeps the matrix
+// pipe busy 0.59 of the time (0.79 with no memory operation at all), two waves together 0.77 - whenever the SIMD partner is away (at
+// the phase barrier, issuing weight DMAs, in its top-of-tile block) the pipe gets single-wave efficiency, and the compiler's placement
+// of a tile's epilogue is what a wave alone cannot hide: twelve conversions / ReLUs packed three to an MFMA gap behind `s_nop 3`
+// hazard padding, an `s_nop 0` in front of every piece's first MFMA.  Here every MFMA, conversion and ReLU of the tile loop is its
+// own `asm volatile` statement - volatile statements keep their source order, so the source order IS the instruction order:
+//   piece k of tile nt:   wait A(pos) | MFMA g0 | op | MFMA g1 | op | MFMA g2 | (ops) | read A(pos + 2)
+// and the epilogue of tile nt - 1 (or of the previous stage's last tile: `pend`) rides one vector instruction per MFMA gap (an
+// MFMA holds the SIMD's vector issue for 8 of its 16 cycles; a 4-5-cycle instruction fits the rest) in the first blocks of tile nt,
+// reading the finished accumulators (`pacc`) while tile nt accumulates into fresh registers.  No hazard padding is needed by
+// construction (and none is inserted: the compiler sees no MFMA): an accumulator is read >= 4 instructions and >= 48 cycles after the
+// MFMA that finished it (a 4-pass MFMA's result is due after 7 wait states), an MFMA re-reads its accumulator after two others,
+// a wait and a read.  Group order of the ops: g0, g1, g2 - group 2, whose last MFMA is the youngest, is touched last.
+template <int F>
+__device__ __forceinline__ void mfma48_first(f32x4& d, const f32x4& a, const typename Prec<F>::BPiece& b, const f32x4& c) {
+  if constexpr (F == 1) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+  else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+}
+// a block's FIRST MFMA carries the counted wait for its A fragment in the same statement (as two statements hipcc puts an `s_nop 0`
+// between them: it takes the wait statement for an unknown writer of the fragment registers); the fragment is an in-out operand, so the
+// compiler cannot touch it between its read statement and this one (tests/test_asm_hazards.py replays the counter on the result)
+#ifdef DN_EXP_NOWAIT
+#define DN_XS_WAIT "; no wait %[n]\n\t"
+#else
+#define DN_XS_WAIT "s_waitcnt lgkmcnt(%[n])\n\t"
+#endif
+template <int F, int NEWER>
+__device__ __forceinline__ void mfma48_first_w(f32x4& d, f32x4& a, const typename Prec<F>::BPiece& b, const f32x4& c) {
+  if constexpr (F == 1) asm volatile(DN_XS_WAIT "v_mfma_f32_16x16x32_bf16 %[d], %[a], %[b], %[c]" : [d] "=&v"(d), [a] "+v"(a) : [b] "v"(b), [c] "v"(c), [n] "n"(NEWER));
+  else asm volatile(DN_XS_WAIT "v_mfma_f32_16x16x32_f16 %[d], %[a], %[b], %[c]" : [d] "=&v"(d), [a] "+v"(a) : [b] "v"(b), [c] "v"(c), [n] "n"(NEWER));
+}
+template <int F, int NEWER>
+__device__ __forceinline__ void mfma48_acc_w(f32x4& d, f32x4& a, const typename Prec<F>::BPiece& b) {
+  if constexpr (F == 1) asm volatile(DN_XS_WAIT "v_mfma_f32_16x16x32_bf16 %[d], %[a], %[b], %[d]" : [d] "+v"(d), [a] "+v"(a) : [b] "v"(b), [n] "n"(NEWER));
+  else asm volatile(DN_XS_WAIT "v_mfma_f32_16x16x32_f16 %[d], %[a], %[b], %[d]" : [d] "+v"(d), [a] "+v"(a) : [b] "v"(b), [n] "n"(NEWER));
+}
+template <int F>
+__device__ __forceinline__ void mfma48_acc(f32x4& d, const f32x4& a, const typename Prec<F>::BPiece& b) {
+  if constexpr (F == 1) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+
+// op S of a hidden tile's epilogue (emit48, one instruction at a time): S = 0 .. 5 convert the pair (2d, 2d + 1) of group S / 2,
+// S = 6 .. 11 (RELU) clamp the packed pair at zero as signed 16-bit integers.  NT: the tile's index in its stage (see emit48).
+template <int F, bool RELU, int NT, int S, class BSet>
+__device__ __forceinline__ void hidden_op48(const f32x4 (&pacc)[3], BSet& bo) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  static_assert(S >= 0 && S < (RELU ? 12 : 6), "op index");
+  constexpr int t = (S % 6) / 2, d = S % 2, e = (NT & 1) * 2 + d;
+  u32x4 w = __builtin_bit_cast(u32x4, bo[t][NT / 2]);
+  if constexpr (S < 6) {
+    const float x = pacc[t][2 * d], y = pacc[t][2 * d + 1];
+    unsigned o;
+    if constexpr (F == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o) : "v"(x), "v"(y));
+    else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(o) : "v"(x), "v"(y));
+    w[e] = o;
+  } else {
+    unsigned o = w[e];
+    asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(o));
+    w[e] = o;
+  }
+  bo[t][NT / 2] = __builtin_bit_cast(typename Prec<F>::BPiece, w);
+}
+// an accumulator element into a plain register (the heads' output rows), as a pinned statement like every other reader of `pacc`
+__device__ __forceinline__ void pick_op48(float& dst, float src) { asm volatile("v_mov_b32 %0, %1" : "=v"(dst) : "v"(src)); }
+
+// How the NP pending ops of the previous tile are laid over the blocks of a tile of KT pieces: the first E blocks, PER to a block;
+// DEADLINE = the first block whose MFMAs read what the ops produce (the last tile of a stage feeds piece (NT_OUT - 1) / 2 of the next).
+constexpr int xs_blocks(int np, int kt, int deadline) {
+  int e = kt < 6 ? kt : 6;
+  if (deadline < e) e = deadline;
+  if (e < 1) e = 1;
+  (void)np;
+  return e;
+}
+constexpr int xs_per(int np, int e) { return (np + e - 1) / e; }
+
+// One GEMM stage, explicit schedule.  NOPS: ops per tile of THIS stage, run by ops(nt_c, s_c) on `pacc` during the following tile;
+// PEND_N / PEND_BY: the ops the caller still owes for the previous stage's last tile (pend(s_c)) and the block of this stage's
+// first tile by which they must be done.  On return `pacc` holds the last tile's accumulators and the caller owes ITS NOPS ops.
+// TRK: as run_stage48 (fp16 range tracker on the stage's input pieces), two dwords per instruction, in the op-free blocks.
+template <int F, int NT_OUT, int KH, int KP, int POS0, bool LAST, int PAD, int NOPS, int PEND_N, int PEND_BY, int TRK = 0, class PipeT, class BH,
+          class BP, class Ops, class Pend>
+__device__ __forceinline__ void run_stage48x(PipeT& pipe, const BH& bh, BP&& bp, unsigned bias_addr, unsigned next_addr, f32x4 (&pacc)[3],
+                                             Ops&& ops, Pend&& pend, unsigned* trk = nullptr) {
+  constexpr int PT = 3, KT = KH + KP;
+  static_assert(KT >= 2 && KH >= 1, "the bias prefetch distance assumes at least two pieces per tile; a tile's first piece is a hidden piece");
+  static_for<NT_OUT>([&](auto nt_c) {
+    constexpr int nt = decltype(nt_c)::value;
+    constexpr int NP = nt == 0 ? PEND_N : NOPS;
+    constexpr int E = xs_blocks(NP, KT, nt == 0 ? PEND_BY : KT);
+    constexpr int PER = xs_per(NP, E);
+    static_assert(PER * E >= NP, "every pending op has a slot");
+    // fp16 tracker: this tile's share of the stage's input dwords, two per instruction, after the pending ops' blocks
+    constexpr int TOT = (F == 2 && TRK != 0) ? PT * KH * 4 : 0;
+    constexpr int Q0 = nt * TOT / NT_OUT, Q1 = (nt + 1) * TOT / NT_OUT;
+    constexpr int NTRK = (TRK == 2) ? (Q1 - Q0) : (Q1 - Q0 + 1) / 2;
+    constexpr int TB = KT - E > 0 ? KT - E : 1;                       // blocks left for them (else: all in the last block)
+    constexpr int TPER = (NTRK + TB - 1) / TB;
+    auto run_op = [&](auto s_c) {
+      constexpr int sidx = decltype(s_c)::value;
+      if constexpr (sidx < NP) {
+        if constexpr (nt == 0) pend(s_c);
+        else ops(std::integral_constant<int, nt - 1>{}, s_c);
+      }
+    };
+    auto run_trk = [&](auto q_c) {
+      constexpr int qi = decltype(q_c)::value;
+      if constexpr (qi < NTRK) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        auto dword = [&](int q) { return __builtin_bit_cast(u32x4, bh[q / (KH * 4)][(q / 4) % KH])[q % 4]; };
+        unsigned tv = *trk;
+        if constexpr (TRK == 2) {
+          const unsigned v = dword(Q0 + qi);
+          unsigned tmp;
+          asm volatile("v_and_b32 %1, 0x7fff7fff, %2\n\tv_pk_max_u16 %0, %0, %1" : "+v"(tv), "=&v"(tmp) : "v"(v));
+        } else {
+          constexpr int qa = Q0 + 2 * qi, qb = (qa + 1 < Q1) ? qa + 1 : qa;
+          const unsigned va = dword(qa), vb = dword(qb);
+          asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(tv) : "v"(va), "v"(vb));
+        }
+        *trk = tv;
+      }
+    };
+    f32x4 acc[PT];
+    static_for<KT>([&](auto k_c) {
+      constexpr int k = decltype(k_c)::value;
+      constexpr int pos = POS0 + nt * KT + k;
+      pipe.template at_position_xs<pos>();
+      f32x4 b = {0.0f, 0.0f, 0.0f, 0.0f};
+      if constexpr (k == 0) b = pipe.template bias_take<1>();
+      constexpr int newer = g48_issued<LAST, POS0 + NT_OUT * KT, PAD>(pos + 1, pos + kPrefetch) + ((k == KT - 1) ? 1 : 0);
+      f32x4& a = pipe.af[pos % kPrefetch];
+      static_for<PT>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        if constexpr (t == 0) {   // (with the wait for A(pos): at most `newer` of our younger reads stay in flight)
+          if constexpr (k == 0) mfma48_first_w<F, newer>(acc[t], a, bh[t][0], b);
+          else if constexpr (k < KH) mfma48_acc_w<F, newer>(acc[t], a, bh[t][k]);
+          else mfma48_acc_w<F, newer>(acc[t], a, bp(t, k - KH));
+        } else if constexpr (k == 0) mfma48_first<F>(acc[t], a, bh[t][0], b);
+        else if constexpr (k < KH) mfma48_acc<F>(acc[t], a, bh[t][k]);
+        else mfma48_acc<F>(acc[t], a, bp(t, k - KH));
+        // the gap behind this MFMA: one op (behind the third MFMA: whatever is left of this block's share)
+        if constexpr (k < E) {
+          if constexpr (t < 2) run_op(std::integral_constant<int, k * PER + t>{});
+          else static_for<(PER > 2 ? PER - 2 : 0)>([&](auto j_c) { run_op(std::integral_constant<int, k * PER + 2 + decltype(j_c)::value>{}); });
+        } else if constexpr (NTRK > 0) {
+          constexpr int kb = (KT - E > 0) ? k - E : 0;
+          if constexpr (t < 2) run_trk(std::integral_constant<int, kb * TPER + t>{});
+          else static_for<(TPER > 2 ? TPER - 2 : 0)>([&](auto j_c) { run_trk(std::integral_constant<int, kb * TPER + 2 + decltype(j_c)::value>{}); });
+        }
+      });
+      if constexpr (KT - E <= 0 && NTRK > 0 && k == KT - 1)   // no op-free block: the tracker's ops behind the tile's last MFMA
+        static_for<NTRK>([&](auto q_c) { run_trk(q_c); });
+      if constexpr ((pos % (2 * kPhasePieces)) < kPhasePieces) pipe.template xs_dma_step<pos % (2 * kPhasePieces)>();
+      if constexpr (g48_issued<LAST, POS0 + NT_OUT * KT, PAD>(pos + kPrefetch, pos + kPrefetch + 1) == 1) pipe.template prefetch<pos>();
+      if constexpr (k == KT - 2) {
+        if constexpr (nt + 1 < NT_OUT) pipe.template bias_prefetch<(nt + 1) * 64>(bias_addr);
+        else if constexpr (LAST) pipe.template bias_prefetch<0>(next_addr);
+        else pipe.template bias_prefetch<NT_OUT * 64>(bias_addr);
+      }
+    });
+#pragma unroll
+    for (int t = 0; t < PT; ++t) pacc[t] = acc[t];
+  });
+}
+
 // rows 4g..4g+3 of output tile NT -> elements (NT & 1) * 4 .. + 3 of B piece NT / 2 (g48_hidden_col)
 // CLAMP (training forward with 8-bit saved tensors): the stage output is limited to e4m3's range (448) before it is rounded
 // to 16 bits, so that the saved byte can be formed straight from the 16-bit pairs (v_cvt_scalef32_pk_fp8_bf16 does not
@@ -163,6 +344,12 @@ __device__ __forceinline__ void emit48(const f32x4& acc, BO& bo) {
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   u32x4 w = __builtin_bit_cast(u32x4, bo[NT / 2]);
+#ifdef DN_EXP_NOEPI   // timing experiment only: raw accumulator bits as the piece's dwords - no convert, no ReLU (1: two moves per tile, 2: one)
+  w[(NT & 1) * 2] = __builtin_bit_cast(unsigned, acc[0]);
+  if (DN_EXP_NOEPI < 2) w[(NT & 1) * 2 + 1] = __builtin_bit_cast(unsigned, acc[2]);
+  bo[NT / 2] = __builtin_bit_cast(typename Prec<F>::BPiece, w);
+  return;
+#endif
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
     f32x2 f = {acc[2 * d], acc[2 * d + 1]};

@@ -166,6 +166,40 @@ def sgpr_base_vmem_violations(ins, need=5):
     return bad
 
 
+def mfma_result_read_violations(ins, need=7):
+    """A vector instruction that is not an MFMA reads a register an MFMA wrote fewer than `need` wait states earlier.
+
+    The explicit-schedule stages (mlp_stage48.h run_stage48x) issue their MFMAs from asm statements, so the compiler's hazard
+    recognizer pads nothing behind them; the conversions / picks that read finished accumulators are placed by construction.
+    gfx950: the result of a 4-pass MFMA (v_mfma_f32_16x16x32_*) is due NumPasses + 3 = 7 wait states (quad-cycles) after its
+    issue.  Counted here in time, as the hardware does: an s_nop N is N + 1, an intervening MFMA 4 (the matrix pipe takes a 4-pass
+    MFMA every 16 cycles), anything else 1.  Another MFMA may name the register at once (accumulator forwarding / its own rule)."""
+    bad = []
+    for i, line in enumerate(ins):
+        op, ops = split_ins(line)
+        if not op.startswith("v_mfma"):
+            continue
+        dst = regs_of(ops[0])
+        states, j = 0, i + 1
+        while j < len(ins) and states < need:
+            nop_, nops = split_ins(ins[j])
+            if nop_ in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                break
+            if nop_.startswith("v_mfma"):
+                states += 4
+            elif nop_ == "s_nop":
+                states += int(nops[0], 0) + 1
+            else:
+                vector = nop_.startswith(("v_", "ds_", "global_", "buffer_", "flat_", "scratch_"))
+                has_dst = nop_.startswith(("v_", "ds_read", "ds_load")) or ("_load_" in nop_ and "_lds_" not in nop_)
+                if vector and regs_of(" ".join(nops[1:] if has_dst else nops)) & dst:   # (sources only: a write-after-write is another rule)
+                    bad.append((i, line, j, ins[j], states))
+                    break
+                states += 1
+            j += 1
+    return bad
+
+
 def m0_lds_dma_violations(ins):
     """SALU writes M0 -> the LDS-DMA (global_load_lds_*) that takes its LDS base from M0: 1 wait state."""
     bad = []

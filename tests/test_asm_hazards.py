@@ -76,6 +76,23 @@ def test_explicit_lds_read_pipeline_is_not_touched_in_flight(kernels):
     assert seen == 22   # forward: 2 widths x {fixed, run-time shape} x {bf16, fp16, bf16 training} + the as-shipped nets' overlapped-encoding instance x {bf16, fp16} + the self-compositing fixed-shape instances (2 widths x {bf16, fp16}); backward: 2 widths x {fixed, run-time}
 
 
+def test_mfma_results_are_read_after_their_wait_states(kernels):
+    """Every MFMA kernel, compiler-scheduled or not: no vector instruction reads an MFMA's destination inside the 7 wait states a
+    4-pass result needs.  Load-bearing for the explicit-schedule render instances, whose MFMAs the hazard recognizer cannot see."""
+    xs = 0
+    for name, ins in mlp_kernels(kernels).items():
+        bad = codeobj.mfma_result_read_violations(ins)
+        assert not bad, (name, bad[:3])
+        if "mlp_forward48_kernel<256, 1, 8, 16u, 1, 0, 0, 0>" in name or "mlp_forward48_kernel<256, 2, 8, 16u, 1, 0, 0, 0>" in name:
+            xs += 1
+            # the explicit schedule really is in place: no hazard padding in front of a conversion, at most one vector instruction
+            # between two MFMAs of the trunk
+            conv = [i for i, line in enumerate(ins) if line.startswith(("v_cvt_pk_bf16_f32", "v_cvt_pk_f16_f32"))]
+            behind_mfma = sum(1 for i in conv if ins[i - 1].startswith("v_mfma"))
+            assert behind_mfma > 0.8 * len(conv) and len(conv) > 900, (name, behind_mfma, len(conv))
+    assert xs == 2
+
+
 def test_the_checkers_catch_planted_hazards():
     """The checks above are only worth something if they fire: plant each hazard in a tiny stream."""
     assert codeobj.sgpr_base_vmem_violations(["v_readfirstlane_b32 s4, v1", "s_nop 2", "global_store_dwordx4 v0, v[4:7], s[4:5]"])
@@ -90,3 +107,8 @@ def test_the_checkers_catch_planted_hazards():
     assert codeobj.lds_read_violations(stream[:2] + ["v_mov_b64_e32 v[30:31], v[12:13]"] + stream[2:])   # the phi copy
     assert codeobj.lds_read_violations(stream[:2] + ["s_waitcnt lgkmcnt(2)"] + stream[3:])               # wait too loose
     assert not codeobj.lds_read_violations(stream[:2] + ["s_branch 12", "v_mov_b64_e32 v[30:31], v[12:13]"])   # an out-of-line block behind a jump
+    m = "v_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[20:23], v[0:3]"
+    assert codeobj.mfma_result_read_violations([m, "s_nop 3", "v_cvt_pk_bf16_f32 v40, v0, v1"])
+    assert not codeobj.mfma_result_read_violations([m, "s_nop 6", "v_cvt_pk_bf16_f32 v40, v0, v1"])
+    assert not codeobj.mfma_result_read_violations([m, m.replace("v[0:3]", "v[4:7]"), "ds_read_b128 v[8:11], v1", "s_waitcnt lgkmcnt(1)", m.replace("v[0:3]", "v[12:15]"),
+                                                    "v_cvt_pk_bf16_f32 v40, v0, v1"])

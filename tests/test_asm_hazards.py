@@ -110,5 +110,5 @@ def test_the_checkers_catch_planted_hazards():
     m = "v_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[20:23], v[0:3]"
     assert codeobj.mfma_result_read_violations([m, "s_nop 3", "v_cvt_pk_bf16_f32 v40, v0, v1"])
     assert not codeobj.mfma_result_read_violations([m, "s_nop 6", "v_cvt_pk_bf16_f32 v40, v0, v1"])
-    assert not codeobj.mfma_result_read_violations([m, m.replace("v[0:3]", "v[4:7]"), "ds_read_b128 v[8:11], v1", "s_waitcnt lgkmcnt(1)", m.replace("v[0:3]", "v[12:15]"),
+    assert not codeobj.mfma_result_read_violations([m, m.replace("v[0:3]", "v[4:7]"), "ds_read_b128 v[8:11], v90", "s_waitcnt lgkmcnt(1)", m.replace("v[0:3]", "v[12:15]"),
                                                     "v_cvt_pk_bf16_f32 v40, v0, v1"])

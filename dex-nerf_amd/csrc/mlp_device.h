@@ -441,13 +441,19 @@ struct DN_PIPE_CLASS {
   // Scalar state per period: this wave's global source and LDS destination of its four pieces of either phase.
   unsigned long long xs_src[2];
   unsigned xs_dst[2];
+  // PERIOD = 32 (one barrier per two phases: the W = 256 instance, see phase_begin2) or 16 (one per phase: phase_begin's ring
+  // accounting - two younger phases of four loads per fetching wave stay in flight - with the fetch of phase p + 4 spread over
+  // positions 0 .. 7 of phase p, wave w at 2w and 2w + 1)
+  template <int PERIOD>
   __device__ __forceinline__ void xs_period_begin() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(PERIOD == kPhasePieces || PERIOD == 2 * kPhasePieces, "barrier period: one or two phases");
+    if constexpr (PERIOD == 2 * kPhasePieces) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #ifndef DN_EXP_NOBARRIER
     __builtin_amdgcn_s_barrier();
 #endif
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < PERIOD / kPhasePieces; ++h) {
       advance_issue();   // (pend_src / pend_dst: this wave's 4 KiB of the phase)
       const unsigned long long bits = reinterpret_cast<unsigned long long>(wsrc + pend_src);
       const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits));
@@ -456,12 +462,13 @@ struct DN_PIPE_CLASS {
       xs_dst[h] = __builtin_amdgcn_readfirstlane(ring_addr + pend_dst);
     }
   }
-  // position Q (0 .. 15) of the period: wave Q / 4 issues two loads (1 KiB each); everyone else skips (branch inside the statement)
-  template <int Q>
+  // fetch step Q of the period (0 .. PERIOD / 2 - 1): ONE wave issues two loads (1 KiB each); everyone else skips (branch inside the statement)
+  template <int PERIOD, int Q>
   __device__ __forceinline__ void xs_dma_step() {
 #ifndef DN_EXP_NODMA
-    constexpr int H = (Q % 4) / 2;            // which of the two phases
-    constexpr int OFF = (Q % 2) * 2048;       // which pair of this wave's four pieces
+    constexpr int STEPS = PERIOD / 8;          // steps per fetching wave: 4 (two phases x two pairs) or 2
+    constexpr int H = (Q % STEPS) / 2;         // which of the period's phases
+    constexpr int OFF = (Q % 2) * 2048;        // which pair of this wave's four pieces of that phase
     unsigned keep;
     asm volatile(
         "s_cmp_lg_u32 %[wave], %[who]\n\t"
@@ -474,19 +481,23 @@ struct DN_PIPE_CLASS {
         "s_mov_b32 m0, %[keep]\n"
         ".Ldn_xs_skip%=:"
         : [keep] "=&s"(keep)
-        : [wave] "s"(wave), [who] "n"(Q / 4), [lds] "s"(xs_dst[H]), [voff] "v"(lane16), [sbase] "s"(xs_src[H]), [o0] "n"(OFF), [o1] "n"(OFF + 1024)
+        : [wave] "s"(wave), [who] "n"(Q / STEPS), [lds] "s"(xs_dst[H]), [voff] "v"(lane16), [sbase] "s"(xs_src[H]), [o0] "n"(OFF), [o1] "n"(OFF + 1024)
         : "memory", "scc");
 #endif
   }
-  template <int POS>
+  template <int PERIOD, int POS>
   __device__ __forceinline__ void at_position_xs() {
-    constexpr int Q = POS % (2 * kPhasePieces);
-    if constexpr (Q == 0) xs_period_begin();
+    if constexpr (POS % PERIOD == 0) xs_period_begin<PERIOD>();
     if constexpr (POS % kPhasePieces == 0) {
       slot_nxt = (slot_nxt + 1 == kRingPhases) ? 0 : slot_nxt + 1;
       rda_cur = slot_cur_base + lane16;
       slot_cur_base = __builtin_amdgcn_readfirstlane(ring_addr + slot_nxt * kSlotBytes);
     }
+  }
+  // the piece position POS has been consumed: its fetch step, if it has one
+  template <int PERIOD, int POS>
+  __device__ __forceinline__ void xs_after_piece() {
+    if constexpr ((POS % PERIOD) < PERIOD / 2) xs_dma_step<PERIOD, POS % PERIOD>();
   }
 #endif
   // phase boundary / mid-phase hooks at position POS of a stream whose barrier period is PH pieces (16, or 32: see above)
@@ -533,13 +544,13 @@ struct DN_PIPE_CLASS {
 
 #if defined(DN_PIPE_ASM_READS) && defined(DN_PIPE_LEADER_DMA)
   // the same for the explicit-schedule pass: the fetch steps of the skipped positions still happen
-  template <int POS, int N>
+  template <int PERIOD, int POS, int N>
   __device__ __forceinline__ void skip_xs() {
     static_for<N>([&](auto i_c) {
       constexpr int pos = POS + decltype(i_c)::value;
       static_assert(pos % kPhasePieces != 0 || decltype(i_c)::value == 0, "padding never crosses a phase");
-      static_assert(pos % (2 * kPhasePieces) != 0, "padding never opens a barrier period");
-      if constexpr ((pos % (2 * kPhasePieces)) < kPhasePieces) xs_dma_step<pos % (2 * kPhasePieces)>();
+      static_assert(pos % PERIOD != 0, "padding never opens a barrier period");
+      xs_after_piece<PERIOD, pos>();
       if constexpr (decltype(i_c)::value >= N - kPrefetch) prefetch<pos>();
     });
     settle<true>();

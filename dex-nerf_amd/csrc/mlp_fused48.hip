@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 #ifdef DN_G48_NO_XS
   constexpr bool XS = false;
 #else
-  constexpr bool XS = FIXED && W == 256 && SAVE == 0 && OVLP == 0 && COMP == 0 && VIEWC != 0;
+  constexpr bool XS = FIXED && SAVE == 0 && OVLP == 0 && COMP == 0 && VIEWC != 0;
 #endif
   constexpr bool ST = !FIXED;   // settle at stage ends
   constexpr bool CL = SAVE != 0;   // clamp stage outputs to e4m3's range (emit48)
@@ -342,8 +342,8 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     float out4[PT][4];
     if constexpr (XS) {
       // ================= explicit schedule (mlp_stage48.h run_stage48x): same stages, same pieces, same arithmetic =================
-      static_assert(PH == 2 * kPhasePieces && DC >= 2 && KDP == 1, "the two-phase barrier period; the view-direction panel is one piece");
-      static_assert((NT * KXP) % PH == 0 && (NT * KH) % PH == 0 && (NT * (KH + KXP)) % PH == 0, "every stage starts at position 0 of a barrier period");
+      static_assert(DC >= 2 && KDP == 1, "a trunk behind layer1; the view-direction panel is one piece");
+      constexpr int PX = PH;   // barrier period: 32 pieces for W = 256 (every stage starts on one), 16 otherwise
       f32x4 pacc[PT];
       auto nothing = [&](auto) {};
       // ---- layer1: xyz encoding -> W, no activation (models.py:238) ----
@@ -353,13 +353,14 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         for (int t = 0; t < PT; ++t)
 #pragma unroll
           for (int k = 0; k < KXP; ++k) pe[t][k] = pe_xyz(t, k);
-        run_stage48x<F, NT, KXP, 0, 0, false, 0, 6, 0, 0>(pipe, pe, no_pe, bias_at(0), 0u, pacc,
+        run_stage48x<F, PX, NT, KXP, 0, 0, false, 0, 6, 0, 0>(pipe, pe, no_pe, bias_at(0), 0u, pacc,
             [&](auto nt_c, auto s_c) { hidden_op48<F, false, decltype(nt_c)::value, decltype(s_c)::value>(pacc, ba); }, nothing);
       }
       bias_tile += NT;
       // ---- trunk (models.py:239-246): each stage's first blocks finish the stage before it ----
       static_for<DC - 1>([&](auto i_c) {
         constexpr int i = decltype(i_c)::value;
+        constexpr int P0 = xs_trunk_pos(i, NT, KH, KXP, MASKC) % PX;
         auto& bin = (i % 2 == 0) ? ba : bb;
         auto& bout = (i % 2 == 0) ? bb : ba;
         auto ops = [&](auto nt_c, auto s_c) { hidden_op48<F, true, decltype(nt_c)::value, decltype(s_c)::value>(pacc, bout); };
@@ -372,19 +373,21 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
           for (int t = 0; t < PT; ++t)
 #pragma unroll
             for (int k = 0; k < KXP; ++k) pe[t][k] = pe_xyz(t, k);
-          run_stage48x<F, NT, KH, KXP, 0, false, 0, 12, PN, BY, (i == 0 ? 2 : 1)>(pipe, bin, [&](int t, int k) { return pe[t][k]; }, bias_at(bias_tile), 0u, pacc, ops, pend, &trk);
+          run_stage48x<F, PX, NT, KH, KXP, P0, false, 0, 12, PN, BY, (i == 0 ? 2 : 1)>(pipe, bin, [&](int t, int k) { return pe[t][k]; }, bias_at(bias_tile), 0u, pacc, ops, pend, &trk);
         } else {
-          run_stage48x<F, NT, KH, 0, 0, false, 0, 12, PN, BY, (i == 0 ? 2 : 1)>(pipe, bin, no_pe, bias_at(bias_tile), 0u, pacc, ops, pend, &trk);
+          run_stage48x<F, PX, NT, KH, 0, P0, false, 0, 12, PN, BY, (i == 0 ? 2 : 1)>(pipe, bin, no_pe, bias_at(bias_tile), 0u, pacc, ops, pend, &trk);
         }
         bias_tile += NT;
       });
       auto& hx = ((DC - 1) % 2 == 0) ? ba : bb;
       auto& hy = ((DC - 1) % 2 == 0) ? bb : ba;
       // ---- fc_alpha (its own 16-row tile, row 0, streamed first) + fc_feat with ReLU (models.py:248-249) ----
-      run_stage48x<F, 1, KH, 0, 0, false, 0, 3, (DC > 1 ? 12 : 6), (NT - 1) / 2>(pipe, hx, no_pe, bias_at(bias_tile), 0u, pacc,
+      constexpr int POS_A = xs_trunk_pos(DC - 1, NT, KH, KXP, MASKC) % PX;
+      run_stage48x<F, PX, 1, KH, 0, POS_A, false, 0, 3, (DC > 1 ? 12 : 6), (NT - 1) / 2>(pipe, hx, no_pe, bias_at(bias_tile), 0u, pacc,
           [&](auto, auto s_c) { constexpr int t = decltype(s_c)::value; pick_op48(out4[t][3], pacc[t][0]); },   // row 0: lane group 0, register 0
           [&](auto s_c) { hidden_op48<F, (DC > 1), NT - 1, decltype(s_c)::value>(pacc, hx); });
-      run_stage48x<F, NT, KH, 0, KH % PH, false, 0, 12, 3, KH, 1>(pipe, hx, no_pe, bias_at(bias_tile + 1), 0u, pacc,
+      constexpr int POS_F = (POS_A + KH) % PX;
+      run_stage48x<F, PX, NT, KH, 0, POS_F, false, 0, 12, 3, KH, 1>(pipe, hx, no_pe, bias_at(bias_tile + 1), 0u, pacc,
           [&](auto nt_c, auto s_c) { hidden_op48<F, true, decltype(nt_c)::value, decltype(s_c)::value>(pacc, hy); },
           [&](auto s_c) { constexpr int t = decltype(s_c)::value; pick_op48(out4[t][3], pacc[t][0]); }, &trk);
       bias_tile += NT + 1;
@@ -411,26 +414,26 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- layers_dir[0] on cat(feat, view) -> W/2, ReLU (models.py:250-252) ----
-      constexpr int POS_D = ((NT + 1) * KH) % PH;
+      constexpr int POS_D = (POS_F + NT * KH) % PX;
       BP8 bg[PT][KH / 2];
       BP8 ped[PT];
 #pragma unroll
       for (int t = 0; t < PT; ++t) ped[t] = *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ped[0]), "+v"(ped[1]), "+v"(ped[2]), "+v"(pipe.af[0]), "+v"(pipe.af[1]), "+v"(pipe.bias_nxt));
-      run_stage48x<F, NT / 2, KH, KDP, POS_D, false, 0, 12, 12, (NT - 1) / 2, 1>(pipe, hy, [&](int t, int) { return ped[t]; }, bias_at(bias_tile), 0u, pacc,
+      run_stage48x<F, PX, NT / 2, KH, KDP, POS_D, false, 0, 12, 12, (NT - 1) / 2, 1>(pipe, hy, [&](int t, int) { return ped[t]; }, bias_at(bias_tile), 0u, pacc,
           [&](auto nt_c, auto s_c) { hidden_op48<F, true, decltype(nt_c)::value, decltype(s_c)::value>(pacc, bg); },
           [&](auto s_c) { hidden_op48<F, true, NT - 1, decltype(s_c)::value>(pacc, hy); }, &trk);
       bias_tile += NT / 2;
       // ---- fc_rgb (models.py:253) ----
-      constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % PH;
+      constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % PX;
       constexpr int END = POS_R + KH / 2;
-      static_assert(END <= PH && (END - 1) / kPhasePieces == POS_R / kPhasePieces, "the tail stays inside one phase");
+      static_assert(END <= PX && (END - 1) / kPhasePieces == POS_R / kPhasePieces, "the tail stays inside one phase");
       constexpr int PAD_R = (kPhasePieces - END % kPhasePieces) % kPhasePieces;
-      static_assert((END + PAD_R) % PH == 0, "a tile pass is a whole number of barrier periods");
-      run_stage48x<F, 1, KH / 2, 0, POS_R, true, PAD_R, 9, 12, (NT / 2 - 1) / 2, 1>(pipe, bg, no_pe, bias_at(bias_tile), bias_at(0), pacc,
+      static_assert((END + PAD_R) % PX == 0, "a tile pass is a whole number of barrier periods");
+      run_stage48x<F, PX, 1, KH / 2, 0, POS_R, true, PAD_R, 9, 12, (NT / 2 - 1) / 2, 1>(pipe, bg, no_pe, bias_at(bias_tile), bias_at(0), pacc,
           [&](auto, auto s_c) { constexpr int sv = decltype(s_c)::value; pick_op48(out4[sv / 3][sv % 3], pacc[sv / 3][sv % 3]); },
           [&](auto s_c) { hidden_op48<F, true, NT / 2 - 1, decltype(s_c)::value>(pacc, bg); }, &trk);
-      if constexpr (PAD_R != 0) pipe.template skip_xs<END, PAD_R>();   // (settles at its end)
+      if constexpr (PAD_R != 0) pipe.template skip_xs<PX, END, PAD_R>();   // (settles at its end)
       else pipe.settle();
       // the last tile's rows: nothing rides behind this stage, so its accumulators are read here - behind the wait states a 4-pass
       // MFMA's result needs (7; the compiler sees no MFMA and pads nothing)

@@ -241,12 +241,18 @@ constexpr int xs_blocks(int np, int kt, int deadline) {
   return e;
 }
 constexpr int xs_per(int np, int e) { return (np + e - 1) / e; }
+// pieces of a fixed-shape tile pass in front of trunk stage i (layer1 + the trunk stages before it)
+constexpr int xs_trunk_pos(int i, int nt, int kh, int kxp, unsigned mask) {
+  int p = nt * kxp;
+  for (int j = 0; j < i; ++j) p += nt * (kh + (((mask >> j) & 1u) ? kxp : 0));
+  return p;
+}
 
 // One GEMM stage, explicit schedule.  NOPS: ops per tile of THIS stage, run by ops(nt_c, s_c) on `pacc` during the following tile;
-// PEND_N / PEND_BY: the ops the caller still owes for the previous stage's last tile (pend(s_c)) and the block of this stage's
+// PX: the barrier period in pieces (Pipe48::xs_period_begin).  PEND_N / PEND_BY: the ops the caller still owes for the previous stage's last tile (pend(s_c)) and the block of this stage's
 // first tile by which they must be done.  On return `pacc` holds the last tile's accumulators and the caller owes ITS NOPS ops.
 // TRK: as run_stage48 (fp16 range tracker on the stage's input pieces), two dwords per instruction, in the op-free blocks.
-template <int F, int NT_OUT, int KH, int KP, int POS0, bool LAST, int PAD, int NOPS, int PEND_N, int PEND_BY, int TRK = 0, class PipeT, class BH,
+template <int F, int PX, int NT_OUT, int KH, int KP, int POS0, bool LAST, int PAD, int NOPS, int PEND_N, int PEND_BY, int TRK = 0, class PipeT, class BH,
           class BP, class Ops, class Pend>
 __device__ __forceinline__ void run_stage48x(PipeT& pipe, const BH& bh, BP&& bp, unsigned bias_addr, unsigned next_addr, f32x4 (&pacc)[3],
                                              Ops&& ops, Pend&& pend, unsigned* trk = nullptr) {
@@ -293,7 +299,7 @@ __device__ __forceinline__ void run_stage48x(PipeT& pipe, const BH& bh, BP&& bp,
     static_for<KT>([&](auto k_c) {
       constexpr int k = decltype(k_c)::value;
       constexpr int pos = POS0 + nt * KT + k;
-      pipe.template at_position_xs<pos>();
+      pipe.template at_position_xs<PX, pos>();
       f32x4 b = {0.0f, 0.0f, 0.0f, 0.0f};
       if constexpr (k == 0) b = pipe.template bias_take<1>();
       constexpr int newer = g48_issued<LAST, POS0 + NT_OUT * KT, PAD>(pos + 1, pos + kPrefetch) + ((k == KT - 1) ? 1 : 0);
@@ -319,7 +325,7 @@ __device__ __forceinline__ void run_stage48x(PipeT& pipe, const BH& bh, BP&& bp,
       });
       if constexpr (KT - E <= 0 && NTRK > 0 && k == KT - 1)   // no op-free block: the tracker's ops behind the tile's last MFMA
         static_for<NTRK>([&](auto q_c) { run_trk(q_c); });
-      if constexpr ((pos % (2 * kPhasePieces)) < kPhasePieces) pipe.template xs_dma_step<pos % (2 * kPhasePieces)>();
+      pipe.template xs_after_piece<PX, pos>();
       if constexpr (g48_issued<LAST, POS0 + NT_OUT * KT, PAD>(pos + kPrefetch, pos + kPrefetch + 1) == 1) pipe.template prefetch<pos>();
       if constexpr (k == KT - 2) {
         if constexpr (nt + 1 < NT_OUT) pipe.template bias_prefetch<(nt + 1) * 64>(bias_addr);

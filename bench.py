@@ -121,19 +121,47 @@ def geometry48(precision):
     return precision in ("bf16", "fp16") and os.environ.get("DEXNERF_BF16_GEOM", "") != "32"
 
 
+KERNEL_SOURCES = ("mlp_fused48.hip", "mlp_stage48.h", "mlp_device.h", "mlp_geo48.h")
+
+
+def kernel_source_sha16():
+    """sha256 (first 16 hex digits) over the sources of the headline kernel as they are in this tree: a committed PMC record names the
+    sources it was collected on (scripts/pmc_collect.py writes the same figure) and is refused when they have changed since."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(REPO, "dex-nerf_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def headline_kernel_name(precision):
+    """Demangled name of the instance the fine-net launch of the headline configuration runs (what rocprofv3 reports)."""
+    if geometry48(precision):
+        return f"mlp_forward48_kernel<256, {2 if precision == 'fp16' else 1}, 8, 16u, 1, 0, 0, 0>"
+    return "mlp_forward_kernel<256, 10, 4"
+
+
 def pmc_record(precision):
-    """The committed rocprofv3 --pmc passes on this exact launch (scripts/pmc_fine_net.sh -> profiles/r0N_pmc_fine_net*.json:
+    """The committed rocprofv3 --pmc passes on this exact launch (scripts/pmc_fine_net.sh -> profiles/r0N_pmc_fine_net_<type>.json:
     FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes, FETCH_SIZE doubled per the gfx950 correction of
-    MI355X_MICROARCH.md).  bench.py itself cannot run the profiler; the records are for the 48-point kernel, per input type."""
-    if not geometry48(precision):
-        return {}
-    for name in (f"r03_pmc_fine_net_{precision}.json", "r02_pmc_fine_net.json" if precision == "bf16" else ""):
-        path = os.path.join(REPO, "profiles", name)
-        if name and os.path.exists(path):
-            rec = json.load(open(path)).get("derived", {})
-            rec["record"] = "profiles/" + name
-            return rec
-    return {}
+    MI355X_MICROARCH.md).  bench.py itself cannot run the profiler.  A record is used only if it names the kernel instance this run
+    times AND was collected on the kernel sources of this tree; otherwise `traffic` is null and `traffic_record` says why."""
+    want = headline_kernel_name(precision)
+    for rnd in ("r04", "r03", "r02"):
+        path = os.path.join(REPO, "profiles", f"{rnd}_pmc_fine_net_{precision}.json")
+        if not os.path.exists(path):
+            continue
+        doc = json.load(open(path))
+        kernel = doc.get("kernel", "")
+        if want not in kernel.replace("dn::", ""):
+            return {"record": f"profiles/{os.path.basename(path)} refused: it profiles `{kernel[:80]}`, this run times `{want}`"}
+        if doc.get("source_sha16") != kernel_source_sha16():
+            return {"record": f"profiles/{os.path.basename(path)} refused: collected on kernel sources {doc.get('source_sha16')}, this tree has {kernel_source_sha16()}"}
+        rec = dict(doc.get("derived", {}))
+        rec["record"] = "profiles/" + os.path.basename(path)
+        return rec
+    return {"record": "no committed PMC record for this precision"}
 
 
 def library_gemm_tflops(dev, precision):
@@ -154,7 +182,8 @@ def library_gemm_tflops(dev, precision):
     return {"shape": f"{m}^3 {precision}", "tflops": 2.0 * m ** 3 * 10 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12}
 
 
-def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pose_id=7):
+def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pose_id=7, nc=NC, nf=NF, luminance=False, h=H, w=W,
+               near=2.0, far=6.0, what_tail="64+128 samples, perturb + noise 0.2, D8/W256 x2"):
     """Secondary metric (SURVEY.md section 8d ii): rays/s of a full training iteration (perturbed sampling, density
     noise, forward + backward + Adam) on n_rays random rays of this rank's view.  With `dist` (N > 1) it is the data-parallel
     step north_star names (reference loop: train_dexnerf_rgb.py:264-289): every rank its own rays, the gradients of both nets
@@ -173,12 +202,12 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pos
     # Adam over the flat parameter buffer: one launch, clears the gradients in the same pass (nerf.FlatAdam; what train_dexnerf.py steps)
     opt = nerf.FlatAdam(bucket, lr=5e-4, zero_grads=True)
     from nerf import synthetic as syn
-    image = torch.rand(1, H, W, 3, device=dev)
-    selector = nerf.MultiViewRaySelector(H, W, [torch.from_numpy(syn.scene_pose(pose_id))], [torch.from_numpy(syn.intrinsic(H, W))], 2.0, 6.0,
+    image = torch.rand(1, h, w, 3, device=dev)
+    selector = nerf.MultiViewRaySelector(h, w, [torch.from_numpy(syn.scene_pose(pose_id))], [torch.from_numpy(syn.intrinsic(h, w))], near, far,
                                          images=image, device=dev)
     # the iteration the build's training driver runs (train_dexnerf.py): device-side pixel draw, the render with its draws made
     # in the kernels, loss head + upstream gradients in one launch, backward, exchange, fused Adam (nerf.FusedTrainStep)
-    fused = nerf.FusedTrainStep(models[0], models[1], selector, cfg, bucket, ex, ed, n_rays, seed=1234 + pose_id)
+    fused = nerf.FusedTrainStep(models[0], models[1], selector, cfg, bucket, ex, ed, n_rays, seed=1234 + pose_id, luminance=luminance)
 
     # ... replayed as HIP graphs: one graph at N = 1; at N > 1 three graphs around the exchange - draw .. fine backward | coarse
     # backward | Adam, each network's all-reduce launched eagerly in between (nerf.GraphedTrainStep)
@@ -202,14 +231,14 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pos
         dt = float(t.item())
     res = {"rays_per_s": world * n_rays / dt, "ms_per_step": dt * 1e3, "rays_per_step_per_gpu": n_rays, "n_gpus": world,
            "hip_graphs_per_step": len(graphed.graphs) if graphed.graphs else 0, "graph_fallback": graphed.fallback_reason,
-           "what": "device pixel draw + ray rows + fwd + loss + bwd + Adam (nerf.FusedTrainStep + nerf.FlatAdam under nerf.GraphedTrainStep), 64+128 samples, perturb + noise 0.2, D8/W256 x2"}
+           "what": "device pixel draw + ray rows + fwd + loss + bwd + Adam (nerf.FusedTrainStep + nerf.FlatAdam under nerf.GraphedTrainStep), " + what_tail}
     # roofline of the step: HBM-bound by construction - the saved activations and gradients are written
     # once by the forward / backward chains and read once by the weight-gradient kernel; MFMA rate beside it (3x forward FLOP)
     nbytes = 0
-    for m, s in ((models[0], NC), (models[1], NC + NF)):
+    for m, s in ((models[0], nc), (models[1], nc + nf)):
         a, mk, g = _ops.train_sizes(m.packed(train=True), n_rays * s, prec=_ops.train_precision(m.packed(train=True)))
         nbytes += 2 * (a + g) + 2 * mk + n_rays * s * (16 + 16 + 4) * 2   # + rf / g_rf / z through compositing
-    flops = 3.0 * n_rays * POINTS_PER_RAY * FLOP_PER_POINT
+    flops = 3.0 * n_rays * (nc + nc + nf) * FLOP_PER_POINT
     res["roofline"] = {"bound": "hbm", "achieved": nbytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / dt / 8e12,
                        "bytes_per_step": nbytes, "mfma_tflops": flops / dt / 1e12,
                        "mfma_frac": flops / dt / 1e12 / PEAK_TFLOPS[nerf.get_precision().split("-")[0]],
@@ -279,6 +308,100 @@ def dex_agreement(out, ref, sel, dev):
             "mean_miss_m": float(miss.mean()), "entries": int(miss.size)}
 
 
+def train_psnr_vs_oracle(dev, iters=200, precision="bf16"):
+    """SURVEY section 8(d) metric (b): training PSNR at a matched iteration count, this library's training iteration (nerf.FusedTrainStep +
+    nerf.FlatAdam: device-side draws, fused loss head, one-launch Adam with the in-kernel schedule - what train_dexnerf.py runs) against the
+    CPU oracle's (autograd through its restatement of the reference path, torch.optim.Adam, the reference's loop:
+    train_dexnerf_rgb.py:229-289).  Same teacher images, same initial weights, same loss / optimizer / schedule; each side draws its
+    own views, pixels and jitter, so the comparison is statistical: PSNR = mse2psnr(MSE_coarse + MSE_fine) of the training batch,
+    averaged over the last 20 iterations before each mark.  4 x 128 nets (the fork's as-shipped architecture), 32 x 32 views,
+    256 rays per step, 32 + 32 samples - sized so the oracle's side takes ~10 s of CPU."""
+    import nerf
+    from nerf import parallel, synthetic as syn
+    from oracle import nerf_oracle as oc
+    hh = ww = 32
+    views, n, nc, nf = 6, 256, 32, 32
+    kw = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+    mode = dict(chunksize=hh * ww, lindisp=False, num_coarse=nc, num_fine=nf, perturb=False, radiance_field_noise_std=0.0, white_background=False)
+    cfg = nerf.CfgNode(dict(dataset=dict(near=2.0, far=6.0, no_ndc=True),
+                            nerf=dict(use_viewdirs=True, train=dict(mode, perturb=True), validation=dict(mode))))
+    ex, ed = nerf.get_embedding_function(10), nerf.get_embedding_function(4)
+    k_mat = torch.from_numpy(syn.intrinsic(hh, ww))
+    poses = [torch.from_numpy(syn.scene_pose(i, n_views=views)) for i in range(views)]
+    before = nerf.get_precision()
+    nerf.set_precision("fp32")
+    try:
+        teacher = []
+        for seed, bias in ((42, -150.0), (43, -20.0)):
+            m = nerf.models.FlexibleNeRFModel(**kw)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(seed, sigma_bias=bias, **kw).items()})
+            teacher.append(m.to(dev))
+        images = []
+        for pose in poses:
+            ro, rd = nerf.get_ray_bundle(hh, ww, float(k_mat[0, 0]), pose.to(dev), k_mat.to(dev))
+            with torch.no_grad():
+                out = nerf.run_one_iter_of_nerf(hh, ww, 1.0, teacher[0], teacher[1], ro, rd, cfg, mode="validation", encode_position_fn=ex,
+                                                encode_direction_fn=ed)
+            images.append(out[3].reshape(hh, ww, 3))
+        torch.manual_seed(1)
+        init = [nerf.models.FlexibleNeRFModel(**kw).state_dict() for _ in range(2)]
+        marks = [m for m in (50, 100, 150, 200, 300, 400) if m <= iters]
+        lr0, factor, decay_steps = 5e-4, 0.1, 250000
+        # ---- this library's iteration
+        nerf.set_precision(precision)
+        models = []
+        for sd in init:
+            m = nerf.models.FlexibleNeRFModel(**kw)
+            m.load_state_dict(sd)
+            models.append(m.to(dev))
+        bucket = parallel.FlatGradBucket(models)
+        opt = nerf.FlatAdam(bucket, lr=lr0, lr_decay_factor=factor, lr_decay_steps=decay_steps, zero_grads=True)
+        selector = nerf.MultiViewRaySelector(hh, ww, poses, [k_mat] * views, 2.0, 6.0, images=torch.stack(images), device=dev)
+        fused = nerf.FusedTrainStep(models[0], models[1], selector, cfg, bucket, ex, ed, n, seed=7, draw_view=True)
+        step = nerf.GraphedTrainStep(fused, opt, eager_iterations=iters + 1)      # (eager: every iteration's loss is read back)
+        losses = []
+        for _ in range(iters):
+            step.step()
+            losses.append(fused.loss3[0:1].clone())
+        mine = torch.cat(losses).cpu().numpy().astype(np.float64)
+        # ---- the CPU oracle's iteration (reference loop)
+        nerf.set_precision("fp32")
+        mc = oc.ModelCfg(**kw)
+        rcfg = oc.RenderCfg(num_coarse=nc, num_fine=nf, near=2.0, far=6.0, perturb=True, m_thres=())
+        sds = [oc.to_torch_sd({k: v.numpy() for k, v in sd.items()}, requires_grad=True) for sd in init]
+        o_opt = torch.optim.Adam([t for sd in sds for t in sd.values()], lr=lr0)
+        gen = np.random.default_rng(0)
+        imgs_cpu = [im.reshape(-1, 3).cpu() for im in images]
+        bundles = [oc.get_ray_bundle(hh, ww, pose, k_mat) for pose in poses]
+        theirs = []
+        t0 = time.perf_counter()
+        for it in range(iters):
+            v = int(gen.integers(views))
+            pix = gen.choice(hh * ww, n, replace=False)
+            ro, rd = bundles[v]
+            out = oc.run_one_iter(ro.reshape(-1, 3)[pix], rd.reshape(-1, 3)[pix], sds[0], sds[1], mc, mc, rcfg)
+            loss = oc.nerf_loss(out, imgs_cpu[v][pix])
+            o_opt.zero_grad(set_to_none=True)
+            loss.backward()
+            o_opt.step()
+            for g in o_opt.param_groups:
+                g["lr"] = lr0 * factor ** (it / decay_steps)
+            theirs.append(float(loss))
+        cpu_s = time.perf_counter() - t0
+        theirs = np.asarray(theirs)
+
+        def psnr_at(curve, m):
+            return float(-10.0 * np.log10(max(curve[max(m - 20, 0): m].mean(), 1e-12)))
+        rows = [{"iteration": m, "hip_psnr_db": psnr_at(mine, m), "oracle_psnr_db": psnr_at(theirs, m)} for m in marks]
+        return {"marks": rows, "final_delta_db": rows[-1]["hip_psnr_db"] - rows[-1]["oracle_psnr_db"], "iterations": iters,
+                "precision": precision, "oracle_cpu_s": cpu_s,
+                "what": "training PSNR (mse2psnr of coarse + fine MSE, mean of the 20 batches before each mark) at matched iteration counts: "
+                        "nerf.FusedTrainStep + nerf.FlatAdam on the device vs autograd through the CPU oracle with torch.optim.Adam; 4x128 nets, "
+                        "6 views of 32x32, 256 rays/step, 32+32 samples, same initial weights, each side its own draws"}
+    finally:
+        nerf.set_precision(before)
+
+
 def cpu_baseline(sample_rays=16384, return_aux=False):
     """The CPU oracle (a restatement of the reference's PyTorch path, pinned to goldens captured from the
     reference) timed on this box's host cores on a bounded sample of the same workload.
@@ -333,9 +456,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus > 1 and world == 1 and "TORCHELASTIC_RUN_ID" not in os.environ:
+        # started plainly (`python bench.py --gpus N`): launch the ranks ourselves - a CHILD torch.distributed.run (this process has
+        # not touched the GPU and never will: no exec), one rank per GPU over RCCL; relay its one JSON line, exit with its code
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        for line in proc.stdout.splitlines():
+            if line.lstrip().startswith("{"):
+                print(line, flush=True)
+            else:
+                print(line, file=sys.stderr, flush=True)
+        raise SystemExit(proc.returncode)
     if os.environ.get("DEXNERF_DIST_BACKEND", "nccl") != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)      # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
@@ -355,6 +492,11 @@ def main():
     from nerf import _hip
     _hip.lib()  # fail loudly if the HIP extension is missing
     nerf.set_precision(args.precision)
+    # The headline is timed in the CONFIG's arithmetic type (BASELINE configs[1]: bf16 - what rounds 1-2 reported): every kernel of the
+    # render in bf16.  The library's own default under set_precision("bf16") - no-grad renders on the fp16 instance of the same MFMA
+    # kernel, for the Dex depth readout - is the leg `default_policy_fp16_render` of the line.
+    if args.precision == "bf16":
+        nerf.set_render_policy("bf16")
     models, cfg, ro, rd, ex, ed = build_scene(dev, rank)
     def note(msg):
         if rank == 0:
@@ -401,12 +543,14 @@ def main():
             "metric": "rays/sec (64+128 samples) + PSNR vs ref, 400x400 scene", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": rdt,
+            "config_dtype": args.precision, "render_dtype": rdt, "library_default_render_dtype": "fp16" if args.precision == "bf16" else rdt,
             "data": "synthetic",
             "precision_policy": {"set_precision": args.precision, "render": rdt, "train": args.precision,
-                                 "what": "nerf.set_precision('bf16'): training kernels in bf16; no-grad renders (what this metric times, and "
-                                         "what the Dex depth sweep of train_dexnerf_rgb.py:391-408 reads) run the fp16 instance of the same "
-                                         "MFMA kernel, guarded by the non-finite count of the compositing passes (falls back to bf16); "
-                                         "DEXNERF_BF16_RENDER=bf16 / nerf.set_render_policy('bf16') renders in bf16 - leg `bf16_render_mode`"},
+                                 "what": "the headline (value, roofline, PSNR, Dex agreement) is the config's type: nerf.set_precision('bf16') + "
+                                         "nerf.set_render_policy('bf16'), every kernel of the render in bf16 (rounds 1-2 reported this; round 3's "
+                                         "headline was the fp16 leg).  The library's DEFAULT under set_precision('bf16') renders no-grad images - and "
+                                         "what the Dex depth sweep of train_dexnerf_rgb.py:391-408 reads - on the fp16 instance of the same MFMA "
+                                         "kernel, guarded against fp16's range (falls back to bf16): leg `default_policy_fp16_render`"},
             "config": {"workload": "C2 render: 400x400 rays/step/GPU, 64 coarse + 128 fine samples, coarse+fine "
                                    "FlexibleNeRFModel D8/W256/skip4 + viewdirs, PE L=10/4, 20 Dex thresholds, "
                                    "validation mode (det. resampling, no noise)",
@@ -416,7 +560,7 @@ def main():
                          "traffic_record": pmc_record(rdt).get("record"),
                          "algorithmic_bytes": H * W * (NC + NF) * 20 + H * W * 44,
                          "matrix_pipe_busy_frac_pmc": pmc_record(rdt).get("matrix_pipe_busy_frac"),
-                         "kernel": (f"mlp_forward48_kernel<256,{2 if rdt == 'fp16' else 1},8,16,1>" if geometry48(rdt) else "mlp_forward_kernel<256,10,4>") + " (fine net, 160000x192 points)",
+                         "kernel": headline_kernel_name(rdt) + " (fine net, 160000x192 points)",
                          "kernel_ms": kt * 1e3, "whole_path_tflops": whole_tf},
         }
         if train_dp is not None:
@@ -431,9 +575,9 @@ def main():
             result["psnr_vs_oracle_db"] = float(-10.0 * np.log10(max(mse, 1e-12)))
             result["dex_vs_oracle"] = dex_agreement(out, ref, sel, dev)
             result["gpu_over_cpu"] = value / world / cb["value"]
-        if args.precision == "bf16" and rdt == "fp16" and not args.no_cpu_baseline:
-            # the same render with the policy off: every kernel in bf16 (what rounds 1-2 reported as the headline)
-            nerf.set_render_policy("bf16")
+        if args.precision == "bf16" and not args.no_cpu_baseline:
+            # the same render on the library's default policy: the fp16 instance of the kernel (range-guarded), round 3's headline
+            nerf.set_render_policy(None)
             try:
                 render(models, cfg, ro, rd, ex, ed)
                 torch.cuda.synchronize()
@@ -445,12 +589,15 @@ def main():
                 kt16, ktf16 = time_dominant_kernel(models, ro, rd, reps=3)
                 rgb16 = out16[3].reshape(-1, 3)[torch.from_numpy(sel).to(dev)].cpu().numpy()
                 mse16 = float(np.mean((rgb16 - ref[3].numpy()) ** 2))
-                result["bf16_render_mode"] = {"value": H * W / dt16, "unit": "rays/s", "kernel_ms": kt16 * 1e3, "tflops": ktf16,
-                                              "frac": ktf16 / PEAK_TFLOPS["bf16"],
-                                              "psnr_vs_oracle_db": float(-10.0 * np.log10(max(mse16, 1e-12))),
-                                              "dex_vs_oracle": dex_agreement(out16, ref, sel, dev)}
+                result["default_policy_fp16_render"] = {"value": H * W / dt16, "unit": "rays/s", "dtype": render_dtype(), "kernel_ms": kt16 * 1e3,
+                                                        "tflops": ktf16, "frac": ktf16 / PEAK_TFLOPS["fp16"],
+                                                        "kernel": headline_kernel_name(render_dtype()),
+                                                        "traffic": pmc_record(render_dtype()).get("hbm_bytes_per_launch"),
+                                                        "traffic_record": pmc_record(render_dtype()).get("record"),
+                                                        "psnr_vs_oracle_db": float(-10.0 * np.log10(max(mse16, 1e-12))),
+                                                        "dex_vs_oracle": dex_agreement(out16, ref, sel, dev)}
             finally:
-                nerf.set_render_policy(None)
+                nerf.set_render_policy("bf16")
         if args.precision == "bf16" and not args.no_cpu_baseline:
             # the same render in the exact-fp32 parity mode (north_star's 1e-4 tolerance holds in this mode only): 3 steps
             nerf.set_precision("fp32")
@@ -484,8 +631,25 @@ def main():
                                                       270, 480, 64, 64, kw_shipped, 167680, 0.3, 4.0)
             result["c4_render"] = other_config_render(dev, rank, "C4 render: 800x800, 64+192 samples, D8/W256 nets",
                                                       800, 800, 64, 192, MODEL_KW, FLOP_PER_POINT, 2.0, 6.0)
+            result["c3_render_128_192"] = other_config_render(dev, rank, "C3 render, the fork's second sampling (config/messytable-obj-edward.yml:136-138): "
+                                                              "270x480, 128+192 samples, 4x128 nets, near 0.3 far 4", 270, 480, 128, 192, kw_shipped, 167680, 0.3, 4.0)
             note(f"C3 {result['c3_render']['value'] / 1e6:.2f} M rays/s ({result['c3_render']['frac']:.3f} of peak), "
+                 f"C3 128+192 {result['c3_render_128_192']['value'] / 1e6:.2f} M rays/s ({result['c3_render_128_192']['frac']:.3f}), "
                  f"C4 {result['c4_render']['value'] / 1e6:.2f} M rays/s ({result['c4_render']['frac']:.3f})")
+            # BASELINE configs[4] as configured: the IR scene's 128 + 256 samples in exact fp32 (train_dexnerf_ir.py; D8/W256 nets on the
+            # MessyTable frame, 270x480) - one image; its training step (luminance loss head, train_nerf_ir.py:260-263) below
+            nerf.set_precision("fp32")
+            try:
+                result["c5_render"] = other_config_render(dev, rank, "C5 render: 270x480, 128+256 samples, D8/W256 nets, exact fp32, near 0.3 far 4",
+                                                          270, 480, 128, 256, MODEL_KW, FLOP_PER_POINT, 0.3, 4.0, steps=1)
+                if not args.no_train:
+                    m5, cfg5, ro5, rd5, _, _ = build_scene(dev, rank, 270, 480, 128, 256, MODEL_KW, 0.3, 4.0)
+                    result["c5_train"] = train_rate(m5, cfg5, ro5, rd5, ex, ed, n_rays=1024, steps=4, nc=128, nf=256, luminance=True, h=270, w=480,
+                                                    near=0.3, far=4.0, what_tail="128+256 samples, perturb + noise 0.2, D8/W256 x2, exact fp32, "
+                                                    "IR loss head (MSE on the luminance of both passes: train_nerf_ir.py:260-263)")
+            finally:
+                nerf.set_precision(args.precision)
+            note(f"C5 render {result['c5_render']['value'] / 1e6:.3f} M rays/s ({result['c5_render']['frac']:.3f} of the fp32 peak)")
         if not args.no_train and world == 1:
             result["train"] = train_rate(models, cfg, ro, rd, ex, ed)
         if not args.no_train and world == 1 and args.precision == "bf16":
@@ -522,6 +686,9 @@ def main():
                 result["train_as_shipped"] = {"error": f"{type(exc).__name__}: {exc}"}
             finally:
                 nerf.set_precision(args.precision)
+        if world == 1 and not args.no_cpu_baseline and not args.no_train:
+            result["train_psnr_vs_oracle"] = train_psnr_vs_oracle(dev, precision=args.precision)
+            note(f"training PSNR at iteration 200: {result['train_psnr_vs_oracle']['marks'][-1]}")
         result["roofline"]["library_gemm"] = library_gemm_tflops(dev, rdt)
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -72,5 +72,12 @@ if p.get("sqB") and p.get("sqA"):
     for k in ("SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_SCA"):
         if k in b:
             d[k + "/WAVE_CYCLES"] = b[k] / wc
+# which kernel sources the record belongs to (bench.py refuses a record collected on other sources)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    out["source_sha16"] = bench.kernel_source_sha16()
+except Exception as exc:  # noqa: BLE001
+    out["source_sha16"] = f"unavailable: {exc}"
 json.dump(out, open(f"gpurun_out/pmc_{tag}.json", "w"), indent=1)
 print(json.dumps(out["derived"], indent=1))

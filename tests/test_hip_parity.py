@@ -1597,6 +1597,41 @@ def test_bench_multi_gpu_leg_rehearsal_two_ranks_one_gpu(dev):
     assert rs["n_gpus"] == 2 and rs["render_sharded_ms"] > rs["all_gather_ms"] > 0 and rs["gathered_bytes_per_rank"] == 800 * 800 * 4 * (10 + 20)
 
 
+def test_bench_started_plainly_with_two_gpus_launches_its_own_ranks(dev):
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run (how the driver starts the N = 1 case): bench.py starts a child
+    torch.distributed.run itself before touching the GPU, relays the one JSON line and exits with the child's code (two gloo ranks on
+    this GPU here; --no-train keeps the rehearsal short)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+    env.update(DEXNERF_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-train"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["dtype"] == line["config_dtype"] == "bf16"
+    assert abs(line["value"] - 2 * 160000 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+
+
+def test_training_psnr_at_matched_iterations_against_the_cpu_oracle(dev):
+    """SURVEY section 8(d) metric (b) as a gate (reference definition train_dexnerf_rgb.py:264-279): 200 iterations of this library's
+    training iteration (nerf.FusedTrainStep + nerf.FlatAdam, device-side draws, bf16 kernels) against 200 iterations of autograd
+    through the CPU oracle from the same initial weights on the same teacher images - the training PSNR at the final mark within 1 dB,
+    every mark within 2 dB (each side makes its own draws: the comparison is statistical), and both well above the starting level."""
+    import bench
+    res = bench.train_psnr_vs_oracle(dev, iters=200, precision="bf16")
+    rows = res["marks"]
+    assert [r["iteration"] for r in rows] == [50, 100, 150, 200]
+    assert abs(res["final_delta_db"]) <= 1.0, rows
+    assert all(abs(r["hip_psnr_db"] - r["oracle_psnr_db"]) <= 2.0 for r in rows), rows
+    assert rows[-1]["hip_psnr_db"] > rows[0]["hip_psnr_db"] + 5.0 and rows[-1]["oracle_psnr_db"] > rows[0]["oracle_psnr_db"] + 5.0, rows
+    _record_measurement("train_psnr_vs_oracle", dict(final_hip=rows[-1]["hip_psnr_db"], final_oracle=rows[-1]["oracle_psnr_db"],
+                                                      delta=res["final_delta_db"], oracle_cpu_s=res["oracle_cpu_s"]))
+
+
 def test_as_shipped_render_instance_with_overlapped_encoding_is_bit_identical(dev):
     """The as-shipped 4 x 128 nets on rays + depths run the forward instance that encodes tile t + 1 inside tile t's trunk stages
     (mlp_forward48_kernel<128, F, 4, 0, 1, 0, 1>: csrc/mlp_fused48.hip).  Same arithmetic, another schedule: its output must equal

@@ -256,6 +256,36 @@ def test_committed_bench_line_follows_the_contract():
     assert abs(line["value"] - rays / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
 
 
+def test_bench_refuses_a_pmc_record_of_another_kernel_or_other_sources(tmp_path, monkeypatch):
+    """bench.py copies `roofline.traffic` from a committed rocprofv3 --pmc record: only from one that names the kernel instance the run
+    times and was collected on the kernel sources of this tree (scripts/pmc_collect.py stamps both)."""
+    import json
+    import sys
+    sys.path.insert(0, REPO)
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    csrc = tmp_path / "dex-nerf_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    for name in bench.KERNEL_SOURCES:
+        (csrc / name).write_text("// " + name)
+    sha = bench.kernel_source_sha16()
+    good = {"kernel": "void dn::mlp_forward48_kernel<256, 1, 8, 16u, 1, 0, 0, 0>(dn::FwdParams, dn::G48Params)", "source_sha16": sha,
+            "derived": {"hbm_bytes_per_launch": 6.4e8, "matrix_pipe_busy_frac": 0.8}}
+    (prof / "r04_pmc_fine_net_bf16.json").write_text(json.dumps(good))
+    rec = bench.pmc_record("bf16")
+    assert rec["hbm_bytes_per_launch"] == 6.4e8 and rec["record"] == "profiles/r04_pmc_fine_net_bf16.json"
+    (prof / "r04_pmc_fine_net_bf16.json").write_text(json.dumps(dict(good, kernel="void dn::mlp_forward48_kernel<256, 2, 8, 16u, 1, 0, 0, 0>(...)")))
+    rec = bench.pmc_record("bf16")
+    assert "hbm_bytes_per_launch" not in rec and "refused" in rec["record"]
+    (prof / "r04_pmc_fine_net_bf16.json").write_text(json.dumps(good))
+    (csrc / bench.KERNEL_SOURCES[0]).write_text("// edited")
+    rec = bench.pmc_record("bf16")
+    assert "hbm_bytes_per_launch" not in rec and "refused" in rec["record"]
+    assert bench.pmc_record("fp16")["record"].startswith("no committed")
+
+
 def test_run_reference_launcher_resolves_the_builds_package(tmp_path):
     """The drop-in launcher (dex-nerf_amd/run_reference.py): a script that sits next to a decoy `nerf/` directory - the
     situation of every reference script (train_dexnerf_rgb.py:15-19 beside nerf-pytorch/nerf/) - must import THIS build's

@@ -308,7 +308,7 @@ def dex_agreement(out, ref, sel, dev):
             "mean_miss_m": float(miss.mean()), "entries": int(miss.size)}
 
 
-def train_psnr_vs_oracle(dev, iters=200, precision="bf16"):
+def train_psnr_vs_oracle(dev, iters=300, precision="bf16"):
     """SURVEY section 8(d) metric (b): training PSNR at a matched iteration count, this library's training iteration (nerf.FusedTrainStep +
     nerf.FlatAdam: device-side draws, fused loss head, one-launch Adam with the in-kernel schedule - what train_dexnerf.py runs) against the
     CPU oracle's (autograd through its restatement of the reference path, torch.optim.Adam, the reference's loop:
@@ -345,7 +345,7 @@ def train_psnr_vs_oracle(dev, iters=200, precision="bf16"):
             images.append(out[3].reshape(hh, ww, 3))
         torch.manual_seed(1)
         init = [nerf.models.FlexibleNeRFModel(**kw).state_dict() for _ in range(2)]
-        marks = [m for m in (50, 100, 150, 200, 300, 400) if m <= iters]
+        marks = [m for m in (100, 200, 300, 400) if m <= iters]
         lr0, factor, decay_steps = 5e-4, 0.1, 250000
         # ---- this library's iteration
         nerf.set_precision(precision)
@@ -386,7 +386,7 @@ def train_psnr_vs_oracle(dev, iters=200, precision="bf16"):
             o_opt.step()
             for g in o_opt.param_groups:
                 g["lr"] = lr0 * factor ** (it / decay_steps)
-            theirs.append(float(loss))
+            theirs.append(float(loss.detach()))
         cpu_s = time.perf_counter() - t0
         theirs = np.asarray(theirs)
 
@@ -653,11 +653,12 @@ def main():
         if not args.no_train and world == 1:
             result["train"] = train_rate(models, cfg, ro, rd, ex, ed)
         if not args.no_train and world == 1 and args.precision == "bf16":
-            # the same iteration with the tensors saved for the backward at 8 bits (same forward bits)
-            nerf.set_precision("bf16-s8")
+            # the same iteration with the tensors saved for the backward at 16 bits on the 32-point training kernels (what 'bf16' meant up to
+            # round 3; 'bf16' now saves at 8 bits on the 48-point kernels - same forward bits)
+            nerf.set_precision("bf16-s16")
             try:
-                models8, cfg8, _, _, _, _ = build_scene(dev, rank)
-                result["train_s8_mode"] = train_rate(models8, cfg8, ro, rd, ex, ed)
+                models16, cfg16, _, _, _, _ = build_scene(dev, rank)
+                result["train_s16_mode"] = train_rate(models16, cfg16, ro, rd, ex, ed)
             finally:
                 nerf.set_precision(args.precision)
             # the same iteration in the exact-fp32 parity mode (BASELINE config 5 trains in fp32): informational
@@ -672,7 +673,7 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(REPO, "dex-nerf_amd"))
                 import train_dexnerf
-                for key, prec in (("train_as_shipped", "bf16"), ("train_as_shipped_s8_mode", "bf16-s8")):
+                for key, prec in (("train_as_shipped", "bf16"), ("train_as_shipped_s16_mode", "bf16-s16")):
                     res = train_dexnerf.main(["--iters", "4000", "--size", "64", "--views", "8", "--num-random-rays", "1024", "--layers", "4",
                                               "--width", "128", "--num-fine", "64", "--validate-every", "0", "--quiet", "--precision", prec])
                     result[key] = {"rays_per_s": res["rays_per_s"], "rays_per_step": 1024, "final_train_psnr_db": res["history"][-1][2],
@@ -688,7 +689,7 @@ def main():
                 nerf.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline and not args.no_train:
             result["train_psnr_vs_oracle"] = train_psnr_vs_oracle(dev, precision=args.precision)
-            note(f"training PSNR at iteration 200: {result['train_psnr_vs_oracle']['marks'][-1]}")
+            note(f"training PSNR at the last mark: {result['train_psnr_vs_oracle']['marks'][-1]}")
         result["roofline"]["library_gemm"] = library_gemm_tflops(dev, rdt)
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -36,7 +36,7 @@ struct BwdParams {
 // dn_set_s8_grad_scale: gradient scale of the 8-bit saved tensors.  Process-wide, not per thread: PyTorch runs the backward of a
 // step on its autograd thread, and the backward-data kernel (which multiplies) and the weight-gradient kernel (which divides)
 // must see the value the caller set on its own thread.
-static std::atomic<float> g_s8_grad_scale{65536.0f};
+static std::atomic<float> g_s8_grad_scale{0.0f};   // 0: per launch, from the largest upstream gradient (safe for any loss reduction / scaling)
 
 constexpr int kBwdWaveLds = 6 * kPieceBytes;  // per wave: 2 output-gradient slots + 4 mask-word slots (1 KiB each)
 

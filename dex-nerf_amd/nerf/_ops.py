@@ -12,20 +12,23 @@ from . import _hip
 from ._hip import MlpDesc, check, f32c, host_floats, lib, ptr, stream
 
 _precision = _hip.PREC_F32
-_save8 = False   # bf16 training keeps its saved activations / gradients at 8 bits (set_precision("bf16-s8"))
+_save8 = False   # bf16 training keeps its saved activations / gradients at 8 bits (the 'bf16' mode; 'bf16-s16' keeps 16)
 
 
 def set_precision(name):
-    """'fp32' (exact fp32 MFMA chains, the parity mode), 'bf16' (bf16 MFMA, fp32 accumulate; render + training),
-    'fp16' (fp16 MFMA at bf16's rate with a 10-bit mantissa: ~57 dB instead of ~42 dB against fp32; render only -
-    training in this mode differentiates the nn.Linear composition) or 'bf16-s8' (bf16 in every kernel; the TRAINING step
-    stores what it saves for the backward - activations as e4m3, layer gradients as e5m2 x a power-of-two scale - at 8 bits and
-    forms the weight gradients with the fp8 MFMA: half the saved-tensor traffic.  Rendering is the bf16 mode's, bit for bit)."""
+    """'fp32' (exact fp32 MFMA chains, the parity mode); 'bf16' (bf16 MFMA, fp32 accumulate; render + training - the TRAINING step
+    stores what it saves for the backward at 8 bits where the 48-point training kernels cover the network (widths 128 / 256, depth <= 9
+    with view directions): activations as e4m3, layer gradients as e5m2 x a power-of-two scale chosen per launch from the largest
+    upstream gradient, weight gradients formed with the fp8 MFMA - half the saved-tensor traffic of 16-bit saves, same forward bits;
+    'bf16-s8' is the older name of this mode); 'bf16-s16' (bf16 with 16-bit saved tensors on the 32-point training kernels: what
+    'bf16' meant up to round 3, and what 'bf16' falls back to for networks the 48-point training kernels do not cover); 'fp16' (fp16
+    MFMA at bf16's rate with a 10-bit mantissa: ~57 dB instead of ~42 dB against fp32; render only - training in this mode
+    differentiates the nn.Linear composition).  Rendering is identical in the three bf16 modes."""
     global _precision, _save8
-    name = str(name).lower()
-    _save8 = name in ("bf16-s8", "bf16_s8")
+    name = str(name).lower().replace("_", "-")
+    _save8 = name in ("bf16", "bf16-s8")
     _precision = {"fp32": _hip.PREC_F32, "f32": _hip.PREC_F32, "bf16": _hip.PREC_BF16, "fp16": _hip.PREC_F16,
-                  "f16": _hip.PREC_F16, "bf16-s8": _hip.PREC_BF16, "bf16_s8": _hip.PREC_BF16}[name]
+                  "f16": _hip.PREC_F16, "bf16-s8": _hip.PREC_BF16, "bf16-s16": _hip.PREC_BF16}[name]
 
 
 _render16 = [None]   # what no-grad renders run in the bf16 modes: None = the environment decides (default "fp16")
@@ -65,9 +68,9 @@ def fp16_range_guard(model):
 
 
 def get_precision():
-    if _save8 and _precision == _hip.PREC_BF16:
-        return "bf16-s8"
-    return {_hip.PREC_F32: "fp32", _hip.PREC_BF16: "bf16", _hip.PREC_F16: "fp16"}[_precision]
+    if _precision == _hip.PREC_BF16:
+        return "bf16" if _save8 else "bf16-s16"
+    return {_hip.PREC_F32: "fp32", _hip.PREC_F16: "fp16"}[_precision]
 
 
 def train_precision(packed):
@@ -80,12 +83,12 @@ def train_precision(packed):
 
 
 def set_s8_grad_scale(scale):
-    """Power of two the saved layer gradients are multiplied by before they are rounded to e5m2 (default 65536 = 2^16).
-    With it, per-point gradients dL/d(pre-activation) between 2.3e-10 (e5m2's smallest subnormal / 2^16; smaller ones flush to
-    zero) and 0.87 (57344 / 2^16; larger ones saturate) are representable, 2 mantissa bits each: the range of a mean-reduced MSE
-    loss over 10^3 .. 10^5 rays from the first iteration to > 40 dB.  A sum-reduced loss, or loss scaling, wants a smaller scale -
-    or scale = 0: every backward-data launch then takes the power of two that puts ITS largest upstream gradient at 2^12 (one more
-    small kernel per launch; s8_grad_stats tells whether that is needed)."""
+    """Power of two the saved layer gradients are multiplied by before they are rounded to e5m2, or 0 (the DEFAULT): every
+    backward-data launch takes the power of two that puts ITS largest finite upstream gradient at 2^12 (one small maximum kernel per
+    launch) - whatever the loss's reduction or scaling.  A fixed scale, e.g. 65536 = 2^16, saves that kernel: with 2^16, per-point
+    gradients dL/d(pre-activation) between 2.3e-10 (e5m2's smallest subnormal / 2^16; smaller ones flush to zero) and 0.87
+    (57344 / 2^16; larger ones saturate) are representable, 2 mantissa bits each - the range of a mean-reduced MSE loss over
+    10^3 .. 10^5 rays from the first iteration to > 40 dB; s8_grad_stats tells whether a fixed scale fits."""
     check(lib().dn_set_s8_grad_scale(float(scale)), "dn_set_s8_grad_scale")
 
 

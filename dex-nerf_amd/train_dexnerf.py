@@ -135,10 +135,10 @@ def main(argv=None):
     ap.add_argument("--ir", action="store_true", help="IR head of train_nerf_ir.py / train_dexnerf_ir.py: MSE on the luminance "
                                                       "0.299 r + 0.587 g + 0.114 b of prediction and target (:260-263)")
     ap.add_argument("--s8-grad-scale", type=float, default=None,
-                    help="bf16-s8: power of two the saved layer gradients are scaled by (default 65536); 0 = chosen per launch from the "
+                    help="bf16: power of two the 8-bit saved layer gradients are scaled by; default 0 = chosen per launch from the "
                          "largest upstream gradient (nerf.set_s8_grad_scale)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16-s8", "fp32"],
-                    help="bf16-s8: bf16 kernels, the tensors saved for the backward at 8 bits (nerf.set_precision)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16-s8", "bf16-s16", "fp32"],
+                    help="bf16 (= bf16-s8): bf16 kernels, the tensors saved for the backward at 8 bits; bf16-s16: at 16 bits (nerf.set_precision)")
     ap.add_argument("--validate-every", type=int, default=500)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--save", default="", help="checkpoint path (reference dict format)")
@@ -323,7 +323,7 @@ def main(argv=None):
             if rank == 0 and not args.quiet:
                 print(f"[train] iter {it:6d} loss {loss_val:.5f} psnr {psnr:.2f} dB lr {lr:.2e} "
                       f"{(time.perf_counter() - t0):.1f} s", flush=True)
-            s8 = nerf.s8_grad_stats() if args.precision == "bf16-s8" else None
+            s8 = nerf.s8_grad_stats() if args.precision in ("bf16", "bf16-s8") else None
             if s8 is not None:
                 s8_saturated_max = max(s8_saturated_max, s8["saturated"])
                 if s8["saturated"] > 1e-4 and rank == 0 and not s8_warned:
@@ -349,7 +349,7 @@ def main(argv=None):
     if t_steady is not None and args.iters - start > 20:
         result["steady_ms_per_iter"] = (t0 + elapsed - t_steady) * 1e3 / (args.iters - start - 20)
     result["hip_graphs"] = len(graphed.graphs) if (graphed is not None and graphed.graphs) else int(graph is not None)   # graphs replayed per iteration
-    if args.precision == "bf16-s8":
+    if args.precision in ("bf16", "bf16-s8"):
         result["s8_saturated_max"] = s8_saturated_max
     if args.save and rank != 0 and os.environ.get("DEXNERF_SAVE_ALL_RANKS"):   # rehearsals: compare the replicas
         torch.save({"model_coarse_state_dict": student[0].state_dict(), "model_fine_state_dict": student[1].state_dict()}, args.save)

@@ -185,18 +185,18 @@ extern "C" int dn_render_rays_train(const dn_mlp_desc* desc_coarse, const void* 
                                 rng_state, kRngStreamNoiseFine);
 }
 
-extern "C" int dn_render_rays_backward(const dn_mlp_desc* desc_coarse, const void* packed_bwd_coarse,
-                                       const dn_mlp_desc* desc_fine, const void* packed_bwd_fine, int precision,
-                                       const float* rays, int ray_stride, int64_t n_rays, int num_coarse, int num_fine,
-                                       float noise_std, int white_background, const float* noise_c, const float* noise_f,
-                                       const float* g_rgb_c, const float* g_depth_c, const float* g_acc_c,
-                                       const float* g_rgb_f, const float* g_depth_f, const float* g_acc_f, void* workspace,
-                                       const void* act_c, const void* masks_c, void* grads_c, const void* act_f,
-                                       const void* masks_f, void* grads_f, float* const* h_dW_c, float* const* h_db_c,
-                                       float* const* h_dW_f, float* const* h_db_f, int nets, const uint32_t* rng_state,
-                                       dn_stream_t stream) {
+extern "C" int dn_render_rays_backward_ws(const dn_mlp_desc* desc_coarse, const void* packed_bwd_coarse,
+                                          const dn_mlp_desc* desc_fine, const void* packed_bwd_fine, int precision,
+                                          const float* rays, int ray_stride, int64_t n_rays, int num_coarse, int num_fine,
+                                          float noise_std, int white_background, const float* noise_c, const float* noise_f,
+                                          const float* g_rgb_c, const float* g_depth_c, const float* g_acc_c,
+                                          const float* g_rgb_f, const float* g_depth_f, const float* g_acc_f, void* workspace,
+                                          const void* act_c, const void* masks_c, void* grads_c, const void* act_f,
+                                          const void* masks_f, void* grads_f, float* const* h_dW_c, float* const* h_db_c,
+                                          float* const* h_dW_f, float* const* h_db_f, int nets, const uint32_t* rng_state,
+                                          void* wg_scratch, size_t wg_scratch_bytes, dn_stream_t stream) {
   if (n_rays == 0) return 0;
-  DN_REQUIRE(rays && workspace && n_rays >= 0 && (nets & ~3) == 0, "dn_render_rays_backward: bad arguments");
+  DN_REQUIRE(rays && workspace && n_rays >= 0 && (nets & ~3) == 0 && (wg_scratch != nullptr || wg_scratch_bytes == 0), "dn_render_rays_backward: bad arguments");
   DN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "dn_render_rays_backward: workspace must be 256-byte aligned");
   Workspace w = carve(workspace, n_rays, num_coarse, num_fine, true);
   int rc;
@@ -215,7 +215,8 @@ extern "C" int dn_render_rays_backward(const dn_mlp_desc* desc_coarse, const voi
     const int64_t n_points = n_rays * samples;
     if ((rc = dn_mlp_backward_data(desc, precision, packed_bwd, w.g_rf, masks, n_points, grads, stream))) return rc;
     if (pair_wgrad) return 0;   // both networks' weight gradients follow in one launch
-    return dn_mlp_weight_grad_all(desc, precision, act, grads, n_points, h_dW, h_db, stream);
+    // (one network at a time: the launches are stream-ordered, so the scratch is free again when the second one starts)
+    return dn_mlp_weight_grad_all_ws(desc, precision, act, grads, n_points, h_dW, h_db, wg_scratch, wg_scratch_bytes, stream);
   };
   // the fine network first: autograd's order too (its graph node is the younger one), and the half a data-parallel caller
   // wants finished first so that its all-reduce overlaps the coarse half
@@ -230,7 +231,23 @@ extern "C" int dn_render_rays_backward(const dn_mlp_desc* desc_coarse, const voi
       return rc;
   }
   if (pair_wgrad)
-    return dn_mlp_weight_grad_pair(desc_fine, precision, act_f, grads_f, n_rays * (num_coarse + num_fine), h_dW_f, h_db_f, act_c, grads_c,
-                                   n_rays * num_coarse, h_dW_c, h_db_c, stream);
+    return dn_mlp_weight_grad_pair_ws(desc_fine, precision, act_f, grads_f, n_rays * (num_coarse + num_fine), h_dW_f, h_db_f, act_c, grads_c,
+                                      n_rays * num_coarse, h_dW_c, h_db_c, wg_scratch, wg_scratch_bytes, stream);
   return 0;
+}
+
+extern "C" int dn_render_rays_backward(const dn_mlp_desc* desc_coarse, const void* packed_bwd_coarse,
+                                       const dn_mlp_desc* desc_fine, const void* packed_bwd_fine, int precision,
+                                       const float* rays, int ray_stride, int64_t n_rays, int num_coarse, int num_fine,
+                                       float noise_std, int white_background, const float* noise_c, const float* noise_f,
+                                       const float* g_rgb_c, const float* g_depth_c, const float* g_acc_c,
+                                       const float* g_rgb_f, const float* g_depth_f, const float* g_acc_f, void* workspace,
+                                       const void* act_c, const void* masks_c, void* grads_c, const void* act_f,
+                                       const void* masks_f, void* grads_f, float* const* h_dW_c, float* const* h_db_c,
+                                       float* const* h_dW_f, float* const* h_db_f, int nets, const uint32_t* rng_state,
+                                       dn_stream_t stream) {
+  return dn_render_rays_backward_ws(desc_coarse, packed_bwd_coarse, desc_fine, packed_bwd_fine, precision, rays, ray_stride, n_rays, num_coarse,
+                                    num_fine, noise_std, white_background, noise_c, noise_f, g_rgb_c, g_depth_c, g_acc_c, g_rgb_f, g_depth_f,
+                                    g_acc_f, workspace, act_c, masks_c, grads_c, act_f, masks_f, grads_f, h_dW_c, h_db_c, h_dW_f, h_db_f, nets,
+                                    rng_state, nullptr, 0, stream);
 }

@@ -548,6 +548,12 @@ struct WgParams {
   int ldw, col_pe0;
   float* db;
   int shape;                      // index into the instantiation table (wg_shape_index)
+  // deterministic reduction (dn_*_ws entry points): workgroup `wg` of the unit stores its partial - [n_real x ldw] dW then [n_real]
+  // db - at part + wg * part_stride with plain stores, and wg_reduce_kernel adds the partials in workgroup order (NULL: fp32 atomics
+  // straight into dW / db, whose order - and so the sum's last bits - changes from launch to launch)
+  float* part;
+  int part_stride;                // floats between consecutive workgroups' partials
+  int n_real;                     // rows of dW / db that exist (custom dY: custom_rows, else the layer's output width)
   // 8-bit saved tensors (DN_PREC_BF16_S8): slots / strides above count 1 KiB UNITS (= two 8-byte-per-lane pieces side by
   // side); dy_odd = which half of its unit a custom dY piece is; out_scale = 1 / (the power of two the gradients were
   // multiplied by before they were rounded to e5m2)
@@ -1126,6 +1132,7 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
   // the memory-side atomic units of the others idle: workgroup `wg` starts wg row-groups further on)
   constexpr int ROW_GROUPS = (IMG_ROWS + 7) / 8;
   const int q0 = wg % ROW_GROUPS;
+  float* part_w = p.part != nullptr ? p.part + static_cast<long long>(wg) * p.part_stride : nullptr;
   auto add_rows = [&](int col0, int n_cols) {
 #pragma unroll
     for (int q = 0; q < ROW_GROUPS; ++q) {
@@ -1135,7 +1142,8 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
 #if DN_WG_EPI == 1
         if (img[n * IMG_LD + lane] == 1.2345f) p.dW[static_cast<long long>(n) * p.ldw + col0 + lane] = 1.0f;
 #else
-        atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col0 + lane, img[n * IMG_LD + lane]);
+        if (p.part != nullptr) part_w[static_cast<long long>(n) * p.ldw + col0 + lane] = img[n * IMG_LD + lane];   // 256 contiguous bytes of this workgroup's partial
+        else atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col0 + lane, img[n * IMG_LD + lane]);
 #endif
       }
     }
@@ -1178,7 +1186,8 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
     const int n = 64 * wave + lane;
     if (n < n_rows) {
 #if DN_WG_EPI != 1
-      atomicAdd(p.db + n, img[n * IMG_LD]);
+      if (p.part != nullptr) part_w[static_cast<long long>(p.n_real) * p.ldw + n] = img[n * IMG_LD];
+      else atomicAdd(p.db + n, img[n * IMG_LD]);
 #endif
     }
   }
@@ -1346,7 +1355,11 @@ __device__ __forceinline__ void weight_grad_unit_f32(const WgParams& p, int wg, 
           if (n >= p.custom_rows) continue;
         }
         const float val = acc[j][r];
-        if (col >= 0) atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col, val);
+        if (p.part != nullptr) {
+          float* part_w = p.part + static_cast<long long>(wg) * p.part_stride;
+          if (col >= 0) part_w[static_cast<long long>(n) * p.ldw + col] = val;
+          else if (col == -2 && p.db != nullptr) part_w[static_cast<long long>(p.n_real) * p.ldw + n] = val;
+        } else if (col >= 0) atomicAdd(p.dW + static_cast<long long>(n) * p.ldw + col, val);
         else if (col == -2 && p.db != nullptr) atomicAdd(p.db + n, val);
       }
     }
@@ -1466,10 +1479,31 @@ __global__ __launch_bounds__(512, 2) void weight_grad_batch_kernel_f32(WgBatch b
   weight_grad_dispatch_f32(p, static_cast<int>(blockIdx.x) - b.wg_begin[u], b.wg_begin[u + 1] - b.wg_begin[u], smem);
 }
 
+// second phase of the deterministic reduction: dW / db += the partials of the unit's workgroups, in workgroup order.  One element per
+// thread and step, consecutive threads on consecutive floats of every partial; blockIdx.y = the unit.
+__global__ __launch_bounds__(256) void wg_reduce_kernel(WgBatch b) {
+  const int u = static_cast<int>(blockIdx.y);
+  const float* part = b.u[u].part;
+  if (part == nullptr) return;
+  const int n_wg = b.wg_begin[u + 1] - b.wg_begin[u];
+  const long long stride = b.u[u].part_stride;
+  const long long n_w = static_cast<long long>(b.u[u].n_real) * b.u[u].ldw;
+  const long long total = n_w + (b.u[u].db != nullptr ? b.u[u].n_real : 0);
+  float* dW = b.u[u].dW;
+  float* db = b.u[u].db;
+  for (long long e = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += static_cast<long long>(gridDim.x) * blockDim.x) {
+    float sum = 0.0f;
+    for (int w = 0; w < n_wg; ++w) sum += part[w * stride + e];
+    if (e < n_w) dW[e] += sum;
+    else db[e - n_w] += sum;
+  }
+}
+
 static int wg_fill(const dn_mlp_desc* desc, const TrainLayout& t, const void* act, const void* grads, int64_t n_points,
                    int g_slot, int n_out, int x_slot, int x_width, int pe_kind, float* dW, int ldw, float* db, WgParams* out,
                    bool s8 = false) {
   const int custom_rows = (n_out < 32) ? n_out : 0;  // fc_rgb (3) / fc_alpha (1) / fc_out (4): one custom dY piece
+  const int n_real = n_out;
   if (custom_rows) n_out = 32;
   DN_REQUIRE(n_out % 32 == 0 && x_width % 32 == 0 && pe_kind >= 0 && pe_kind <= 2, "weight_grad: bad layer shape");
   WgParams p{};
@@ -1484,6 +1518,7 @@ static int wg_fill(const dn_mlp_desc* desc, const TrainLayout& t, const void* ac
   p.pe_L = pe_kind == 1 ? desc->num_encoding_fn_xyz : desc->num_encoding_fn_dir;
   p.pe_kind = pe_kind;
   p.dW = dW; p.ldw = ldw; p.col_pe0 = x_width; p.db = db;
+  p.n_real = n_real; p.part = nullptr; p.part_stride = 0;
   p.shape = wg_shape_index(n_out / 32, x_width / 32, pe_tiles, custom_rows > 0);
   if (p.shape < 0) {
     set_error("weight_grad: no kernel instance for a %d x (%d + %d) layer%s", n_out, x_width, 32 * pe_tiles, custom_rows ? " (custom dY)" : "");
@@ -1588,7 +1623,10 @@ static int wg_add_network(const dn_mlp_desc* desc, int precision, bool s8, const
 bool weight_grad_pair_fits(const dn_mlp_desc& d) { return 2 * (d.num_layers + (d.use_viewdirs ? 4 : 1)) <= kWgMaxUnits; }
 
 // share the workgroups (one per CU) among the batch's units and launch
-static int wg_launch_batch(WgBatch& b, const long long* unit_tiles, bool f32, bool s8, dn_stream_t stream) {
+constexpr long long wg_part_stride(int n_real, int ldw) { return ((static_cast<long long>(n_real) * (ldw + 1) + 63) / 64) * 64; }
+
+static int wg_launch_batch(WgBatch& b, const long long* unit_tiles, bool f32, bool s8, dn_stream_t stream, void* scratch = nullptr,
+                           size_t scratch_bytes = 0) {
   int rc;
   const int n_units = b.n_units;
   // (one workgroup per CU.  Two per CU on half the LDS - an instance of the W = 128 layer shapes only, 128 VGPRs - was tried for the
@@ -1619,6 +1657,22 @@ static int wg_launch_batch(WgBatch& b, const long long* unit_tiles, bool f32, bo
   for (int i = 0; i < n_units; ++i) {
     if (share[i] > unit_tiles[i]) share[i] = static_cast<int>(unit_tiles[i]);  // idle workgroups would exit at once anyway
     b.wg_begin[i + 1] = b.wg_begin[i] + share[i];
+  }
+  // deterministic reduction: a partial per workgroup in the caller's scratch, added up in workgroup order by a second launch
+  bool two_phase = false;
+  if (scratch != nullptr) {
+    long long floats = 0;
+    for (int i = 0; i < n_units; ++i) floats += static_cast<long long>(b.wg_begin[i + 1] - b.wg_begin[i]) * wg_part_stride(b.u[i].n_real, b.u[i].ldw);
+    DN_REQUIRE(static_cast<size_t>(floats) * sizeof(float) <= scratch_bytes && (reinterpret_cast<uintptr_t>(scratch) & 255) == 0,
+               "weight gradients: the reduction scratch holds %zu bytes, %lld are needed (dn_mlp_weight_grad_scratch_bytes), 256-byte aligned",
+               scratch_bytes, floats * 4);
+    float* at = static_cast<float*>(scratch);
+    for (int i = 0; i < n_units; ++i) {
+      b.u[i].part = at;
+      b.u[i].part_stride = static_cast<int>(wg_part_stride(b.u[i].n_real, b.u[i].ldw));
+      at += static_cast<long long>(b.wg_begin[i + 1] - b.wg_begin[i]) * b.u[i].part_stride;
+    }
+    two_phase = true;
   }
   if ((rc = f32 ? wg_attr(weight_grad_batch_kernel_f32) : (s8 ? wg_attr(weight_grad_batch_kernel_s8) : wg_attr(weight_grad_batch_kernel)))) return rc;
 #ifdef DN_WG_STAMP   // diagnostic build: synchronous, allocates, prints - never part of the shipped library
@@ -1657,13 +1711,31 @@ static int wg_launch_batch(WgBatch& b, const long long* unit_tiles, bool f32, bo
     }
   }
 #endif
-  return check_launch("dn_mlp_weight_grad_all");
+  if ((rc = check_launch("dn_mlp_weight_grad_all"))) return rc;
+  if (two_phase) {
+    hipLaunchKernelGGL(wg_reduce_kernel, dim3(24, static_cast<unsigned>(n_units)), dim3(256), 0, as_stream(stream), b);
+    return check_launch("weight-gradient reduction");
+  }
+  return 0;
 }
 
 }  // namespace dn
 
-extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, const void* act, const void* grads,
-                                      int64_t n_points, float* const* h_dW, float* const* h_db, dn_stream_t stream) {
+// Bytes of reduction scratch dn_mlp_weight_grad_all_ws (n_networks = 1) / dn_mlp_weight_grad_pair_ws (2) need for networks of this
+// architecture: one partial (dW + db of the layer it works on) per workgroup of the launch, every workgroup priced at the largest layer.
+extern "C" size_t dn_mlp_weight_grad_scratch_bytes(const dn_mlp_desc* desc, int n_networks) {
+  if (desc == nullptr || n_networks < 1 || n_networks > 2) return 0;
+  const int W = desc->hidden_size;
+  const int dim_xyz = 3 + 6 * desc->num_encoding_fn_xyz, dim_dir = 3 + 6 * desc->num_encoding_fn_dir;
+  const int widest = W + (dim_xyz > dim_dir ? dim_xyz : dim_dir);
+  const int n_units = n_networks * (desc->num_layers + (desc->use_viewdirs ? 4 : 1));
+  int total_wg = dn::device_cus();
+  if (total_wg < n_units) total_wg = n_units;
+  return static_cast<size_t>(total_wg + n_units) * static_cast<size_t>(dn::wg_part_stride(W, widest)) * sizeof(float);
+}
+
+extern "C" int dn_mlp_weight_grad_all_ws(const dn_mlp_desc* desc, int precision, const void* act, const void* grads, int64_t n_points,
+                                         float* const* h_dW, float* const* h_db, void* scratch, size_t scratch_bytes, dn_stream_t stream) {
   const bool s8 = precision == DN_PREC_BF16_S8;
   if (s8) precision = DN_PREC_BF16;   // same layouts and slots, half-size pieces
   int rc = validate_desc(desc, precision);
@@ -1674,15 +1746,21 @@ extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, co
   WgBatch b{};
   long long unit_tiles[kWgMaxUnits];
   if ((rc = wg_add_network(desc, precision, s8, act, grads, n_points, h_dW, h_db, b, unit_tiles, "dn_mlp_weight_grad_all"))) return rc;
-  return wg_launch_batch(b, unit_tiles, precision == DN_PREC_F32, s8, stream);
+  return wg_launch_batch(b, unit_tiles, precision == DN_PREC_F32, s8, stream, scratch, scratch_bytes);
+}
+
+extern "C" int dn_mlp_weight_grad_all(const dn_mlp_desc* desc, int precision, const void* act, const void* grads,
+                                      int64_t n_points, float* const* h_dW, float* const* h_db, dn_stream_t stream) {
+  return dn_mlp_weight_grad_all_ws(desc, precision, act, grads, n_points, h_dW, h_db, nullptr, 0, stream);
 }
 
 // The weight gradients of TWO networks of one architecture - the coarse and the fine network of a training step - in ONE launch:
 // the workgroups are shared among all their layers by cost x points, so a layer's gradient is the sum of half as many partials as
 // with two launches and the launch's fixed costs (pipeline fill, the reduction epilogue, the launch itself) are paid once.
-extern "C" int dn_mlp_weight_grad_pair(const dn_mlp_desc* desc, int precision, const void* act_a, const void* grads_a, int64_t n_points_a,
-                                       float* const* h_dW_a, float* const* h_db_a, const void* act_b, const void* grads_b,
-                                       int64_t n_points_b, float* const* h_dW_b, float* const* h_db_b, dn_stream_t stream) {
+extern "C" int dn_mlp_weight_grad_pair_ws(const dn_mlp_desc* desc, int precision, const void* act_a, const void* grads_a, int64_t n_points_a,
+                                          float* const* h_dW_a, float* const* h_db_a, const void* act_b, const void* grads_b,
+                                          int64_t n_points_b, float* const* h_dW_b, float* const* h_db_b, void* scratch, size_t scratch_bytes,
+                                          dn_stream_t stream) {
   const bool s8 = precision == DN_PREC_BF16_S8;
   if (s8) precision = DN_PREC_BF16;
   int rc = validate_desc(desc, precision);
@@ -1693,7 +1771,14 @@ extern "C" int dn_mlp_weight_grad_pair(const dn_mlp_desc* desc, int precision, c
   long long unit_tiles[kWgMaxUnits];
   if ((rc = wg_add_network(desc, precision, s8, act_a, grads_a, n_points_a, h_dW_a, h_db_a, b, unit_tiles, "dn_mlp_weight_grad_pair"))) return rc;
   if ((rc = wg_add_network(desc, precision, s8, act_b, grads_b, n_points_b, h_dW_b, h_db_b, b, unit_tiles, "dn_mlp_weight_grad_pair"))) return rc;
-  return wg_launch_batch(b, unit_tiles, precision == DN_PREC_F32, s8, stream);
+  return wg_launch_batch(b, unit_tiles, precision == DN_PREC_F32, s8, stream, scratch, scratch_bytes);
+}
+
+extern "C" int dn_mlp_weight_grad_pair(const dn_mlp_desc* desc, int precision, const void* act_a, const void* grads_a, int64_t n_points_a,
+                                       float* const* h_dW_a, float* const* h_db_a, const void* act_b, const void* grads_b,
+                                       int64_t n_points_b, float* const* h_dW_b, float* const* h_db_b, dn_stream_t stream) {
+  return dn_mlp_weight_grad_pair_ws(desc, precision, act_a, grads_a, n_points_a, h_dW_a, h_db_a, act_b, grads_b, n_points_b, h_dW_b, h_db_b,
+                                    nullptr, 0, stream);
 }
 
 extern "C" int dn_mlp_weight_grad(const dn_mlp_desc* desc, int precision, const void* act, const void* grads,

@@ -29,6 +29,7 @@ EXPORTS = (
     "dn_render_train_workspace_bytes", "dn_render_rays_train", "dn_render_rays_backward",
     "dn_set_s8_grad_scale", "dn_mlp_pack_parts", "dn_fp16_range_guard", "dn_select_rays_draw", "dn_mse2_loss", "dn_rng_fill", "dn_mlp_pack_train_pair",
     "dn_adam_step", "dn_pack_ray_rows", "dn_mlp_weight_grad_pair",
+    "dn_mlp_weight_grad_scratch_bytes", "dn_mlp_weight_grad_all_ws", "dn_mlp_weight_grad_pair_ws", "dn_render_rays_backward_ws",
 )
 
 
@@ -85,6 +86,11 @@ def _declare(lib):
     lib.dn_mlp_weight_grad_all.argtypes = [POINTER(MlpDesc), c_int, vp, vp, c_int64, POINTER(c_void_p), POINTER(c_void_p), vp]
     lib.dn_mlp_weight_grad_pair.argtypes = [POINTER(MlpDesc), c_int, vp, vp, c_int64, POINTER(c_void_p), POINTER(c_void_p), vp, vp, c_int64,
                                             POINTER(c_void_p), POINTER(c_void_p), vp]
+    lib.dn_mlp_weight_grad_scratch_bytes.argtypes = [POINTER(MlpDesc), c_int]
+    lib.dn_mlp_weight_grad_scratch_bytes.restype = c_size_t
+    lib.dn_mlp_weight_grad_all_ws.argtypes = [POINTER(MlpDesc), c_int, vp, vp, c_int64, POINTER(c_void_p), POINTER(c_void_p), vp, c_size_t, vp]
+    lib.dn_mlp_weight_grad_pair_ws.argtypes = [POINTER(MlpDesc), c_int, vp, vp, c_int64, POINTER(c_void_p), POINTER(c_void_p), vp, vp, c_int64,
+                                               POINTER(c_void_p), POINTER(c_void_p), vp, c_size_t, vp]
     lib.dn_set_s8_grad_scale.argtypes = [c_float]
     lib.dn_fp16_range_guard.argtypes = [POINTER(MlpDesc)]
     lib.dn_render_train_workspace_bytes.argtypes = [c_int64, c_int, c_int]
@@ -95,6 +101,9 @@ def _declare(lib):
     lib.dn_render_rays_backward.argtypes = [POINTER(MlpDesc), vp, POINTER(MlpDesc), vp, c_int, fp, c_int, c_int64, c_int, c_int,
                                             c_float, c_int, fp, fp, fp, fp, fp, fp, fp, fp, vp, vp, vp, vp, vp, vp, vp,
                                             POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int, vp, vp]
+    lib.dn_render_rays_backward_ws.argtypes = [POINTER(MlpDesc), vp, POINTER(MlpDesc), vp, c_int, fp, c_int, c_int64, c_int, c_int,
+                                               c_float, c_int, fp, fp, fp, fp, fp, fp, fp, fp, vp, vp, vp, vp, vp, vp, vp,
+                                               POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int, vp, vp, c_size_t, vp]
     lib.dn_select_rays_draw.argtypes = [c_int, c_int, fp, vp, c_int, c_float, c_float, vp, c_int64, fp, c_int, fp, fp, vp, vp]
     lib.dn_mse2_loss.argtypes = [fp, fp, fp, c_int64, c_int, fp, fp, fp, vp, vp]
     lib.dn_rng_fill.argtypes = [vp, ctypes.c_uint32, c_int64, c_int, fp, vp]

@@ -452,6 +452,28 @@ def mlp_weight_grad(packed, act, grads, n_points, g_slot, n_out, x_slot, x_width
                                    x_slot, x_width, pe_kind, ptr(d_w), d_w.shape[1], ptr(d_b), stream()), "dn_mlp_weight_grad")
 
 
+_DETERMINISTIC_WGRAD = [True]
+
+
+def set_deterministic_weight_gradients(on):
+    """True (default): the weight-gradient launches of the training paths reduce their workgroups' partials in a fixed order (a partial
+    per workgroup in a scratch buffer + a second small launch: dn_*_ws) - a training run is then a pure function of its seed, bit for
+    bit, like the reference on the CPU.  False: fp32 atomics straight into the gradients (no scratch; the sum's last bits change from
+    launch to launch)."""
+    _DETERMINISTIC_WGRAD[0] = bool(on)
+
+
+def _wgrad_scratch(packed, n_networks):
+    """(tensor, bytes) of reduction scratch for this architecture, or (None, 0).  A fresh stream-ordered allocation per call (the
+    caching allocator hands the same block back every step; inside a graph capture it belongs to the graph's pool)."""
+    if not _DETERMINISTIC_WGRAD[0]:
+        return None, 0
+    nbytes = int(lib().dn_mlp_weight_grad_scratch_bytes(ctypes.byref(packed.desc), int(n_networks)))
+    if nbytes <= 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=packed.buffer.device), nbytes
+
+
 def mlp_weight_grad_all(packed, act, grads, n_points, shapes, s8=False, prec=None):
     """bf16 buffers: every layer's (dW, db) in one launch.  `shapes` = [(out, in)] in linear_modules() order; returns
     [(dW, db)] as views of ONE zero-filled fp32 buffer.  s8: the buffers are in the 8-bit unit layout (convert_saved_s8)."""
@@ -467,7 +489,8 @@ def mlp_weight_grad_all(packed, act, grads, n_points, shapes, s8=False, prec=Non
     bp = (c_void_p * len(out))(*[b.data_ptr() for _, b in out])
     if prec is None:
         prec = _hip.PREC_BF16_S8 if s8 else packed.precision
-    check(lib().dn_mlp_weight_grad_all(ctypes.byref(packed.desc), prec, ptr(act), ptr(grads), n_points, wp, bp, stream()),
+    scratch, nbytes = _wgrad_scratch(packed, 1)
+    check(lib().dn_mlp_weight_grad_all_ws(ctypes.byref(packed.desc), prec, ptr(act), ptr(grads), n_points, wp, bp, ptr(scratch), nbytes, stream()),
           "dn_mlp_weight_grad_all")
     return out
 
@@ -477,8 +500,9 @@ def mlp_weight_grad_all_into(packed, act, grads, n_points, views, prec=None):
     `.grad` views of a parallel.FlatGradBucket, already zeroed for this step)."""
     wp = (c_void_p * len(views))(*[w.data_ptr() for w, _ in views])
     bp = (c_void_p * len(views))(*[b.data_ptr() for _, b in views])
-    check(lib().dn_mlp_weight_grad_all(ctypes.byref(packed.desc), packed.precision if prec is None else prec, ptr(act), ptr(grads),
-                                       n_points, wp, bp, stream()), "dn_mlp_weight_grad_all")
+    scratch, nbytes = _wgrad_scratch(packed, 1)
+    check(lib().dn_mlp_weight_grad_all_ws(ctypes.byref(packed.desc), packed.precision if prec is None else prec, ptr(act), ptr(grads),
+                                          n_points, wp, bp, ptr(scratch), nbytes, stream()), "dn_mlp_weight_grad_all")
 
 
 def run_network_pts(packed, pts, viewdirs, samples_per_ray):
@@ -718,12 +742,18 @@ def render_rays_backward(packed_c, packed_f, saved, g_c, g_f, views_c, views_f, 
     wc, bc = arrays(views_c if nets & 1 else None)
     wf, bf = arrays(views_f if (fine and nets & 2) else None)
     gs = [None if g is None else f32c(g) for g in tuple(g_c) + tuple(g_f)]
-    check(lib().dn_render_rays_backward(
+    k_nets = 2 if (fine and nets == 3) else 1
+    scratch, scratch_bytes = _wgrad_scratch(packed_c, k_nets)
+    if fine:   # (two architectures: the larger need)
+        other = _wgrad_scratch(packed_f, k_nets)
+        if other[1] > scratch_bytes:
+            scratch, scratch_bytes = other
+    check(lib().dn_render_rays_backward_ws(
         ctypes.byref(packed_c.desc), ptr(packed_c.buffers_bwd[prec]),
         ctypes.byref(packed_f.desc) if fine else None, ptr(packed_f.buffers_bwd[prec]) if fine else None, prec,
         ptr(saved["rays"]), saved["rays"].shape[1], n, nc, nf, saved["noise_std"], int(saved["white"]),
         ptr(saved["noise_c"]), ptr(saved["noise_f"]), ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]), ptr(gs[5]),
         ptr(saved["ws"]), ptr(saved["act_c"]), ptr(saved["masks_c"]), ptr(grads_c), ptr(saved["act_f"]), ptr(saved["masks_f"]),
-        ptr(grads_f), wc, bc, wf, bf, int(nets), ptr(saved.get("rng_state")), stream()), "dn_render_rays_backward")
+        ptr(grads_f), wc, bc, wf, bf, int(nets), ptr(saved.get("rng_state")), ptr(scratch), scratch_bytes, stream()), "dn_render_rays_backward")
     _note_s8_record(grads_c, prec); _note_s8_record(grads_f, prec)
-    return grads_c, grads_f   # (kept alive by the caller until the stream has consumed them: PyTorch's caching allocator is stream-ordered)
+    return grads_c, grads_f, scratch   # (kept alive by the caller until the stream has consumed them: PyTorch's caching allocator is stream-ordered)

@@ -7,20 +7,7 @@
 
 #include "mlp_layout.h"
 
-// The DN_EXP_* / DN_STORE_POLICY_ID hooks below are timing ablations (some of them knowingly UNSAFE: no cross-wave ordering,
-// loosened waits).  They compile only in an ablation build - scripts/build_exp.sh passes -DDN_ABLATION_BUILD, the Makefile
-// never does - so a stray -D cannot put one into the shipped library.
-#if !defined(DN_ABLATION_BUILD) && \
-    (defined(DN_EXP_NODMA) || defined(DN_EXP_NOREAD) || defined(DN_EXP_SHALLOW) || defined(DN_EXP_LOOSEWAIT) ||    \
-     defined(DN_EXP_NOBARRIER) || defined(DN_EXP_REGSTAGE) || defined(DN_EXP_ROTATE) || defined(DN_EXP_SETPRIO) || \
-     defined(DN_EXP_NOPIN) || defined(DN_EXP_NOSAVE) || defined(DN_EXP_NOSETTLE) || defined(DN_STAMP) || defined(DN_STORE_POLICY_ID) || \
-     defined(DN_WG_NOREAD) || defined(DN_WG_NOSTAGE) || defined(DN_WG_STAMP) || defined(DN_WG_EPI) || defined(DN_WG_LOAD_POLICY_ID) ||  \
-     defined(DN_WG_ONLY) || defined(DN_G48_PREFETCH) || defined(DN_G48_COMPILER_READS) || defined(DN_G48_SYMMETRIC_DMA) ||               \
-     defined(DN_G48_PRIO) || defined(DN_G48_BARRIER_EVERY_PHASE) || defined(DN_G48_SKIP_PE_FROM_LDS) ||                                 \
-     defined(DN_EXP_NOEPI) || defined(DN_EXP_NOWAIT) || defined(DN_EXP_NOTOP) || defined(DN_G48_EPI_PIN) || defined(DN_EXP_HALF) || defined(DN_EXP_ONLY_PAPER) || defined(DN_G48_NO_XS) ||                                                          \
-     (defined(DN_PREFETCH) && !defined(DN_PREFETCH_SET_BY_KERNEL_SOURCE)))
-#error "DN_EXP_* / DN_WG_* / DN_G48_* / DN_PREFETCH / DN_STORE_POLICY_ID are ablation hooks: build them with scripts/build_exp.sh (-DDN_ABLATION_BUILD), never into libdexnerf_hip.so"
-#endif
+#include "dn_ablation.h"
 
 namespace dn {
 

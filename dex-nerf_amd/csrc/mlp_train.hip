@@ -1491,9 +1491,17 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(WgBatch b) {
   const long long total = n_w + (b.u[u].db != nullptr ? b.u[u].n_real : 0);
   float* dW = b.u[u].dW;
   float* db = b.u[u].db;
+  // (the order is fixed, not sequential: four running sums over the partials w = 0, 1, 2, 3 (mod 4), combined at the end - four loads in
+  // flight per thread instead of a chain of dependent ones)
   for (long long e = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += static_cast<long long>(gridDim.x) * blockDim.x) {
-    float sum = 0.0f;
-    for (int w = 0; w < n_wg; ++w) sum += part[w * stride + e];
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int w = 0;
+    for (; w + 3 < n_wg; w += 4) {
+      const float a = part[w * stride + e], b2 = part[(w + 1) * stride + e], c = part[(w + 2) * stride + e], d = part[(w + 3) * stride + e];
+      s0 += a; s1 += b2; s2 += c; s3 += d;
+    }
+    for (; w < n_wg; ++w) s0 += part[w * stride + e];
+    const float sum = (s0 + s1) + (s2 + s3);
     if (e < n_w) dW[e] += sum;
     else db[e - n_w] += sum;
   }
@@ -1713,7 +1721,7 @@ static int wg_launch_batch(WgBatch& b, const long long* unit_tiles, bool f32, bo
 #endif
   if ((rc = check_launch("dn_mlp_weight_grad_all"))) return rc;
   if (two_phase) {
-    hipLaunchKernelGGL(wg_reduce_kernel, dim3(24, static_cast<unsigned>(n_units)), dim3(256), 0, as_stream(stream), b);
+    hipLaunchKernelGGL(wg_reduce_kernel, dim3(48, static_cast<unsigned>(n_units)), dim3(256), 0, as_stream(stream), b);
     return check_launch("weight-gradient reduction");
   }
   return 0;

@@ -112,6 +112,107 @@ __global__ __launch_bounds__(512, 2) void ceiling_kernel(const char* wstream, un
   if (s == 12345.678f) out[blockIdx.x * 512 + threadIdx.x] = s;   // keep the chain alive
 }
 
+// mode 3: what a 3-way bf16 split of an fp32 product would issue (x = hi + mid + lo, 8 mantissa bits each; the six partial products
+// hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid reach fp32's 24 bits): per k-step THREE weight fragments from LDS and SIX MFMAs into one
+// 16-point accumulator group - three activation sets of 32 registers per 16 points, so a wave holds ONE group where the bf16 kernel holds
+// three - and per output tile the split of the four accumulators into hi / mid / lo pieces (~22 vector instructions).  Upper bound for
+// an "fp32x" mode: no weight DMA (the 3x larger stream would arrive at ~2x today's byte rate), no encodings, no heads.
+__global__ __launch_bounds__(512, 2) void split3_kernel(const char* wstream, int iters, float* out, unsigned long long* clk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  bf16x8 b[3][8];   // hi / mid / lo pieces of one 16-point group, 256 features
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        unsigned h = (lane * 2654435761u) ^ ((t * 8 + k) * 40503u + e * 9176u + blockIdx.x * 7919u);
+        h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+        const float v = ((h & 0xffff) / 65536.0f - 0.5f) * 2.0f;
+        b[t][k][e] = static_cast<__bf16>(t == 0 ? (v > 0.0f ? v : 0.0f) : v * (t == 1 ? 0.004f : 0.00002f));
+      }
+  for (unsigned i = threadIdx.x; i < kSlots * kPhase * kPiece / 16; i += 512)
+    reinterpret_cast<f32x4*>(smem)[i] = reinterpret_cast<const f32x4*>(wstream)[i];
+  __syncthreads();
+  const unsigned ring = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
+  const unsigned lane16 = lane * 16;
+  f32x4 af[2][3];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) af[s][c] = reinterpret_cast<const f32x4*>(smem + (s * 3 + c) * kPiece)[lane];
+  unsigned long long t0 = 0, r0 = 0;
+  if (threadIdx.x == 0) { asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)); }
+  f32x4 acc = {0, 0, 0, 0};
+  float keep = 0.0f;
+  unsigned rd = 6;   // next piece triple to read (pieces, modulo the ring)
+  for (int it8 = 0; it8 < iters / 8; ++it8) {
+    // eight output tiles per trip (tile j writes piece j of the three sets: compile-time register indices)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // one output tile: 8 k-steps x 6 MFMAs, then the split of its four values
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(af[k & 1][0]), "+v"(af[k & 1][1]), "+v"(af[k & 1][2]));
+        mfma<1>(acc, af[k & 1][0], b[0][k]);   // hi hi
+        mfma<1>(acc, af[k & 1][0], b[1][k]);   // hi mid
+        mfma<1>(acc, af[k & 1][1], b[0][k]);   // mid hi
+        mfma<1>(acc, af[k & 1][0], b[2][k]);   // hi lo
+        mfma<1>(acc, af[k & 1][2], b[0][k]);   // lo hi
+        mfma<1>(acc, af[k & 1][1], b[1][k]);   // mid mid
+        const unsigned base = ring + rd * kPiece + lane16;
+        rd = (rd + 3 >= kSlots * kPhase - 3) ? 0 : rd + 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[k & 1][c]) : "v"(base), "n"(0));
+      }
+      // split: hi = bf16(x), r = x - hi, mid = bf16(r), lo = bf16(r - mid)  (ReLU first), into piece j of the three sets
+      asm volatile("s_nop 7" ::: "memory");
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = acc[e] > 0.0f ? acc[e] : 0.0f;
+        const __bf16 hi = static_cast<__bf16>(x);
+        const float r = x - static_cast<float>(hi);
+        const __bf16 mid = static_cast<__bf16>(r);
+        const __bf16 lo = static_cast<__bf16>(r - static_cast<float>(mid));
+        b[0][j][(j & 1) * 4 + e] = hi; b[1][j][(j & 1) * 4 + e] = mid; b[2][j][(j & 1) * 4 + e] = lo;
+      }
+      keep += acc[0];
+      acc = f32x4{0, 0, 0, 0};
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]));
+  if (threadIdx.x == 0) {
+    unsigned long long t1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1));
+    clk[blockIdx.x * 2] = t1 - t0;
+    clk[blockIdx.x * 2 + 1] = r1 - r0;
+  }
+  if (keep == 12345.678f) out[blockIdx.x * 512 + threadIdx.x] = keep;
+}
+
+static void run_split3(const char* w, float* out, unsigned long long* clk, int cus) {
+  const int iters = 60000;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(split3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSlots * kPhase * kPiece);
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  float best = 1e30f;
+  for (int rep = 0; rep < 6; ++rep) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL(split3_kernel, dim3(cus), dim3(512), kSlots * kPhase * kPiece, 0, w, iters, out, clk);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    if (rep >= 3 && ms < best) best = ms;
+  }
+  std::vector<unsigned long long> h(cus * 2);
+  hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
+  double ghz = 0; for (int i = 0; i < cus; ++i) ghz += double(h[2 * i]) / double(h[2 * i + 1]) * 0.1; ghz /= cus;
+  const double mfma_flop = double(cus) * 8 * iters * 48.0 * (16.0 * 16 * 32 * 2);
+  printf("%-34s %8.2f ms  %7.1f TFLOP/s of bf16 MFMAs = %6.1f TFLOP/s of fp32-grade products (/6) = %.2f x the 157.3 TFLOP/s fp32-MFMA peak   in-kernel clock %.3f GHz\n",
+         "bf16 x 3 split (16 points / wave)", best, mfma_flop / best / 1e9, mfma_flop / best / 1e9 / 6.0, mfma_flop / best / 1e9 / 6.0 / 157.3, ghz);
+}
+
 template <int F, int MODE>
 static void run(const char* name, const char* w, unsigned bytes, float* out, unsigned long long* clk, int cus) {
   const int iters = 6000;
@@ -158,5 +259,6 @@ int main() {
   run<2, 0>("fp16 registers only", w16, bytes, out, clk, cus);
   run<2, 1>("fp16 + A fragments from LDS", w16, bytes, out, clk, cus);
   run<2, 2>("fp16 + LDS + weight DMA ring", w16, bytes, out, clk, cus);
+  run_split3(w, out, clk, cus);
   return 0;
 }

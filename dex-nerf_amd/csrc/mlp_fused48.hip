@@ -17,11 +17,17 @@ namespace dn {
 // compile-time element of the lane's rotated point (g48_pe_col).  No per-slot decode and no selects (per-lane compares
 // land in SGPR pairs; dozens of them per block spilled scalars into VGPR lanes and activation pieces to scratch).
 // One hardware sine per slot: cos(2 pi r) = sin(2 pi (r + 1/4)) (revolutions, as mlp_device.h encode_pieces in bf16 mode).
+// The table's frequency is in REVOLUTIONS per unit (f / 2 pi, folded in by the pack kernel: for the reference's default power-of-two
+// frequencies (x f) (1 / 2 pi) and x (f / 2 pi) round identically - a scaling by 2^k is exact - so the encodings are the ones of
+// rounds 1-3 bit for bit; two multiplies became one).  Only slots 0-2 of a lane group can be identity columns (g48_pe_col: rank 0);
+// the others are plain sines (padding: frequency 0, phase 0 -> sin 0 = 0) and skip the two-weight mix: 4 vector instructions per slot
+// instead of 7, and the top-of-tile block is 48 slots per lane (profiles/r04_headline_schedule.md: 4 % of the pass).
+template <bool MAY_BE_IDENTITY = true>
 __device__ __forceinline__ float pe_value(float xc, f32x4 entry) {
-  const float arg = xc * entry[0];
-  const float rev = __builtin_amdgcn_fractf(arg * 0.15915494309189535f) + entry[1];
+  const float rev = __builtin_amdgcn_fractf(xc * entry[0]) + entry[1];
   const float s = __builtin_amdgcn_sinf(rev);
-  return entry[2] * xc + entry[3] * s;   // weights are 0 / 1: exact
+  if constexpr (MAY_BE_IDENTITY) return entry[2] * xc + entry[3] * s;   // weights are 0 / 1: exact
+  else return s;
 }
 
 // (x, y, z) rotated so that element k is coordinate (k + g) % 3 of the point.  Bitwise selects: written with ?: hipcc
@@ -268,7 +274,9 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         for (int k = 0; k < KXP; ++k) {
           BP8 piece;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) piece[e] = static_cast<Elem>(pe_value(xr[(k * 8 + e) % 3], tabx[k * 8 + e]));
+          for (int e = 0; e < 8; ++e)
+            piece[e] = static_cast<Elem>((k * 8 + e < 3) ? pe_value<true>(xr[(k * 8 + e) % 3], tabx[k * 8 + e])
+                                                         : pe_value<false>(xr[(k * 8 + e) % 3], tabx[k * 8 + e]));
           *reinterpret_cast<BP8*>(pex + (t * KXP + k) * kPieceBytes) = piece;
           pk[k] = piece;
         }
@@ -407,7 +415,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
           rotate3(v, ln >> 4, vr);
           BP8 piece;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) piece[e] = static_cast<Elem>(pe_value(vr[e % 3], tabd[e]));
+          for (int e = 0; e < 8; ++e) piece[e] = static_cast<Elem>((e < 3) ? pe_value<true>(vr[e % 3], tabd[e]) : pe_value<false>(vr[e % 3], tabd[e]));
           *reinterpret_cast<BP8*>(pex + t * kPieceBytes) = piece;
           __builtin_amdgcn_sched_barrier(0);
         });
@@ -498,8 +506,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
         constexpr int tq = m / 16, k = (m % 16) / 8, e = m % 8, u = k * 8 + e;
         static_assert(KXP == 2 && PT == 3, "48 slots per lane");
         const float xc = xr_n[tq][u % 3];
-        const float arg = xc * tfreq[u];                                            // (pe_value, op for op)
-        const float rev = __builtin_amdgcn_fractf(arg * 0.15915494309189535f) + tphase[u];
+        const float rev = __builtin_amdgcn_fractf(xc * tfreq[u]) + tphase[u];       // (pe_value, op for op)
         const float sv = __builtin_amdgcn_sinf(rev);
         float val = sv;
         if constexpr (u < 3) val = tw_id[u] * xc + tw_sin[u] * sv;
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
             rotate3(v, ln >> 4, vr);
             BP8 piece;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) piece[e] = static_cast<Elem>(pe_value(vr[e % 3], tabd[e]));
+            for (int e = 0; e < 8; ++e) piece[e] = static_cast<Elem>((e < 3) ? pe_value<true>(vr[e % 3], tabd[e]) : pe_value<false>(vr[e % 3], tabd[e]));
             if constexpr (OVL) ped_now[t] = piece;   // (the stash holds the NEXT tile's xyz pieces by now: same lane, no need to park)
             else *reinterpret_cast<BP8*>(pex + t * kPieceBytes) = piece;
             if constexpr (SAVE != 0) {
@@ -780,7 +787,7 @@ __device__ __forceinline__ void pack48_body(const NetLayout& L, const PackPtrs& 
     if (c >= 0 && c < 3) entry[2] = 1.0f;
     else if (c >= 3) {
       const int qq = c - 3, f = qq / 6, r = qq % 6;
-      entry[0] = kind_pe == 1 ? tabs.fx[f] : tabs.fd[f];
+      entry[0] = (kind_pe == 1 ? tabs.fx[f] : tabs.fd[f]) * 0.15915494309189535f;   // revolutions per unit (pe_value)
       entry[1] = r < 3 ? 0.0f : 0.25f;
       entry[3] = 1.0f;
     }

@@ -40,7 +40,9 @@ for it in range(n_cfg):
         d = (o48 - o32).abs() / sc; e48 = (o48 - ref).abs() / sc; e32 = (o32 - ref).abs() / sc
         big = ref.numel() >= 2000
         if not torch.isfinite(o48).all(): msgs.append(f"{form}: non-finite")
-        if float(d.max()) > 8e-2 or (big and float(d.mean()) > 1e-4): msgs.append(f"{form}: 48 vs 32 mean {float(d.mean()):.2e} max {float(d.max()):.2e}")
+        # (linear frequency sampling: the 48-point kernel multiplies by f / 2 pi, the 32-point one by f and then by 1 / 2 pi - for the
+        # default power-of-two frequencies the two round identically, for others the sine's argument differs by an ulp: ~1e-4 rad at 2^9 x)
+        if float(d.max()) > 8e-2 or (big and float(d.mean()) > (1e-4 if logs else 5e-4)): msgs.append(f"{form}: 48 vs 32 mean {float(d.mean()):.2e} max {float(d.max()):.2e}")
         if big and abs(float(e48.mean()) - float(e32.mean())) > 0.15 * float(e32.mean()) + 1e-5: msgs.append(f"{form}: vs fp32 mean 48 {float(e48.mean()):.2e} / 32 {float(e32.mean()):.2e}")
     tag = f"W{width} D{D} skip{skip} view{int(view)} LX{lx} log{int(logs)} rays{n_rays}x{s}"
     print(("BAD  " if msgs else "ok   ") + tag + ("  " + "; ".join(msgs) if msgs else ""), flush=True)

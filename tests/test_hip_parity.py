@@ -1088,6 +1088,47 @@ def test_48_point_geometry_against_32_point_and_fp32(dev, monkeypatch, prec16):
         nerf.set_precision("fp32")
 
 
+@pytest.mark.parametrize("prec16", ["bf16", "fp16"])
+def test_explicit_schedule_instances_equal_the_compiler_scheduled_kernel_bit_for_bit(dev, monkeypatch, prec16):
+    """The fixed-shape render instances run the explicit schedule (mlp_stage48.h run_stage48x: MFMAs, conversions and ReLUs as ordered
+    asm statements, the previous tile's epilogue in the MFMA gaps, weight DMAs one wave at a time); the run-time-shape kernel
+    (DEXNERF_G48_RUNTIME_SHAPE=1) is compiler-scheduled from the round-1 stage loop.  Same pieces, same products, same accumulation
+    order: the outputs must be EQUAL - paper net (32-piece barrier period) and as-shipped net (16-piece period, points form: the
+    non-overlapped instance), one point .. more tiles than workgroups (every workgroup's first-tile prologue and its steady state,
+    the stream wrap, the tail padding), both input forms."""
+    import nerf
+    from nerf import _ops, synthetic as syn
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    nerf.set_precision(prec16)
+    try:
+        for (D, width) in ((8, 256), (4, 128)):
+            kw = dict(num_layers=D, hidden_size=width, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=True)
+            m = nerf.models.FlexibleNeRFModel(**kw)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(7 + D, sigma_gain=5.0, sigma_bias=0.0, **kw).items()})
+            m = m.to(dev)
+            pk = m.packed()
+            for n_rays, s in ((1, 1), (1, 385), (77, 5), (700, 192), (2100, 100)):      # 2100 x 100 = 547 tiles of 384 points > 256 workgroups
+                pts = torch.randn(n_rays, s, 3, generator=gen).to(dev)
+                vd = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=gen), dim=-1).to(dev)
+                rays = torch.cat([torch.randn(n_rays, 3, generator=gen).to(dev), vd * 1.5, torch.zeros(n_rays, 2, device=dev), vd], -1).contiguous()
+                z = torch.sort(torch.rand(n_rays, s, generator=gen) * 4 + 2, -1)[0].to(dev).contiguous()
+                for form in ("pts", "rays"):
+                    def run():
+                        with torch.no_grad():
+                            if form == "pts":
+                                return _ops.run_network_pts(pk, pts.reshape(-1, 3), vd, s)
+                            return _ops.run_network_rays(pk, rays, z)
+                    monkeypatch.setenv("DEXNERF_G48_NO_OVERLAP", "1")      # (as-shipped net, rays form: the plain fixed instance)
+                    fixed = run()
+                    monkeypatch.setenv("DEXNERF_G48_RUNTIME_SHAPE", "1")
+                    runtime = run()
+                    monkeypatch.delenv("DEXNERF_G48_RUNTIME_SHAPE")
+                    monkeypatch.delenv("DEXNERF_G48_NO_OVERLAP")
+                    assert torch.isfinite(fixed).all() and torch.equal(fixed, runtime), (prec16, width, n_rays, s, form)
+    finally:
+        nerf.set_precision("fp32")
+
+
 # ---- the kernel / configurations the bench line times, gated against the reference-recorded golden and the oracle ----
 def dex_agreement(dex, dex_ref, tol_scale=TOL):
     """Dex-depth agreement between two (K, N) stacks: fraction of (threshold, ray) entries within tol_scale * max|ref|,

@@ -233,7 +233,7 @@ def test_committed_bench_line_follows_the_contract():
     """The bench line committed under profiles/ (written by bench.py on an MI355X) carries every field the driver's
     contract names, with the roofline and cpu_baseline objects."""
     import json
-    path = os.path.join(REPO, "profiles", "r02_bench_bf16.json")
+    path = os.path.join(REPO, "profiles", "r04_bench.json")
     line = json.loads(open(path).read().strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -249,6 +249,15 @@ def test_committed_bench_line_follows_the_contract():
     assert line["fp32_mode"]["frac"] == pytest.approx(line["fp32_mode"]["tflops"] / 157.3)
     tr = line["train"]["roofline"]
     assert tr["bound"] == "hbm" and tr["unit"] == "GB/s" and abs(tr["frac"] - tr["achieved"] / tr["peak"]) < 1e-9
+    # round 4: the headline is the config's dtype, the library's default render policy is a leg; every BASELINE config has a leg;
+    # the measured traffic comes from a PMC record that names the timed kernel instance
+    assert line["dtype"] == line["config_dtype"] == line["render_dtype"] == "bf16" and line["default_policy_fp16_render"]["dtype"] == "fp16"
+    assert roof["traffic_record"] == "profiles/r04_pmc_fine_net_bf16.json" and roof["traffic"] > roof["algorithmic_bytes"]
+    for leg in ("c3_render", "c3_render_128_192", "c4_render", "c5_render"):
+        assert line[leg]["value"] > 0 and 0.0 < line[leg]["frac"] < 1.0, leg
+    assert line["c5_render"]["dtype"] == "fp32" and line["c5_train"]["rays_per_s"] > 0 and line["train_s16_mode"]["ms_per_step"] > line["train"]["ms_per_step"]
+    marks = line["train_psnr_vs_oracle"]["marks"]
+    assert marks[-1]["iteration"] == 300 and abs(line["train_psnr_vs_oracle"]["final_delta_db"]) <= 1.0
     cb = line["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     # value = rays of all ranks / time: consistent with ms_per_step

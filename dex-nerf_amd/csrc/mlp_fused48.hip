@@ -61,9 +61,15 @@ template <int W, int F, int DC = 0, unsigned MASKC = 0, int VIEWC = 0, int SAVE 
 __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdParams p, G48Params q) {
   static_assert(SAVE == 0 || (SAVE == 2 && F == 1), "saved tensors: the 8-bit layout, bf16 arithmetic");
   static_assert(COMP == 0 || (SAVE == 0 && OVLP == 0 && DC > 0), "in-kernel compositing: a render instance whose xyz stash is free at the end of a pass");
-  constexpr bool OVL = OVLP != 0;
+  constexpr bool OVL = OVLP == 1;
   static_assert(!OVL || (DC >= 3 && MASKC == 0u && VIEWC != 0 && SAVE == 0 && W == 128),
                 "overlapped encoding: fixed shape, no skip layer (the stash is dead after layer1), two trunk stages of 24 output tiles");
+  // OVLP = 2 (the paper network's render instance on rays + depths): tile t + 1's xyz encoding rides in the MFMA gaps of tile t's
+  // view-direction stage, one vector instruction at a time (explicit schedule: run_stage48x's hook) - the registers of the dead trunk
+  // set are free there, the stash is dead (the view-direction pieces are in registers), and the encoding table comes from LDS one
+  // entry per slot, read a block ahead.  Only a workgroup's first tile is encoded at the top.
+  constexpr bool OVX = OVLP == 2;
+  static_assert(!OVX || (W == 256 && DC > 0 && VIEWC != 0 && SAVE == 0 && COMP == 0), "in-stage encoding: the explicit-schedule W = 256 render instance");
   constexpr int VSETS = OVL ? 3 : 2;           // view-direction row sets: the inputs of tile t + 2 arrive during tile t
   constexpr int IN_ROWS = 7 + 3 * VSETS;
   constexpr bool FIXED = DC > 0;
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 #ifdef DN_G48_NO_XS
   constexpr bool XS = false;
 #else
-  constexpr bool XS = FIXED && SAVE == 0 && OVLP == 0 && COMP == 0 && VIEWC != 0;
+  constexpr bool XS = FIXED && SAVE == 0 && (OVLP == 0 || OVLP == 2) && COMP == 0 && VIEWC != 0;
 #endif
   constexpr bool ST = !FIXED;   // settle at stage ends
   constexpr bool CL = SAVE != 0;   // clamp stage outputs to e4m3's range (emit48)
@@ -219,6 +225,13 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       if (u < 3) { tw_id[u] = e[2]; tw_sin[u] = e[3]; }
     }
   }
+  // OVX: which lanes hold an identity column in slots 0 - 2 (lane group 0, by the table's identity weight): three lane masks
+  unsigned long long idm[3] = {0ull, 0ull, 0ull};
+  if constexpr (OVX) {
+    const f32x4* tabx = reinterpret_cast<const f32x4*>(tab_lds) + (lane >> 4) * 16;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) idm[u] = __ballot(tabx[u][2] != 0.0f);
+  }
   const int n_tiles = static_cast<int>(p.n_tiles);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, vset = (VSETS == 2 ? vset ^ 1 : (vset == 2 ? 0 : vset + 1))) {
     // training forward: this wave's three point groups' saved-unit bases and its mask words' (s8-48 layout, mlp_geo48.h) - wave-
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 #ifdef DN_EXP_NOTOP   // timing experiment only: no top-of-tile block (the stash keeps whatever it held; inputs are not staged)
     if (false) {
 #else
-    if (!OVL || first_tile) {
+    if ((!OVL && !OVX) || first_tile) {
 #endif
       const int ln = fresh_lane();
       const int j = ln & 15;
@@ -423,14 +436,103 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
       __builtin_amdgcn_sched_barrier(0);
       // ---- layers_dir[0] on cat(feat, view) -> W/2, ReLU (models.py:250-252) ----
       constexpr int POS_D = (POS_F + NT * KH) % PX;
+      constexpr int KT_D = KH + KDP;
       BP8 bg[PT][KH / 2];
       BP8 ped[PT];
+      // OVX state: the two values of a dword pair, two table entries in flight (frequency in revolutions, phase), LDS addresses
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      float ev[2] = {0.0f, 0.0f};
+      f32x2 tbl[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+      unsigned tab_addr_v = 0u, stash_addr_v = 0u;
+      float in_n[PT][7];
+      if constexpr (OVX) {
+        static_assert(kEncOps <= enc_begin((NT / 2) * KT_D, KT_D), "the view-direction stage has a gap for every encoding op");
+        // the next tile's inputs: their DMAs were issued a whole tile ago (the first tile's: at its top).  Waves 4-7 issue no weight
+        // DMAs, so no counted wait of theirs pushes input DMAs through: they wait here (their queue holds nothing else but the last
+        // output stores); waves 0-3 have passed dozens of barrier-period waits (vmcnt(0)) since.  Branch inside the statement.
+        {
+          const unsigned must_wait = __builtin_amdgcn_readfirstlane(wave >= 4 ? 1u : 0u);
+          asm volatile("s_cmp_eq_u32 %0, 0\n\t"
+                       "s_cbranch_scc1 .Ldn_ovx_nowait%=\n\t"
+                       "s_waitcnt vmcnt(0)\n"
+                       ".Ldn_ovx_nowait%=:" ::"s"(must_wait) : "scc", "memory");
+        }
+        const int ln = fresh_lane();
+        const int j = ln & 15;
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+          for (int c = 0; c < 7; ++c) in_n[t][c] = inbuf[c * PPW + t * 16 + j];
+        tab_addr_v = pipe.ring_addr + kRingBytes + static_cast<unsigned>(q.bias_bytes) + static_cast<unsigned>(ln >> 4) * 256u;
+        stash_addr_v = pipe.ring_addr + kRingBytes + static_cast<unsigned>(q.bias_bytes) + kG48TableBytes + wave * (PT * KXP * kPieceBytes) + static_cast<unsigned>(ln) * 16u;
+        asm volatile("ds_read_b64 %0, %1" : "=v"(tbl[0]) : "v"(tab_addr_v));    // slot 0's table entry (the others ride in the stage)
+      }
 #pragma unroll
       for (int t = 0; t < PT; ++t) ped[t] = *reinterpret_cast<const BP8*>(pex_of(pipe.lane16 >> 4) + t * kPieceBytes);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ped[0]), "+v"(ped[1]), "+v"(ped[2]), "+v"(pipe.af[0]), "+v"(pipe.af[1]), "+v"(pipe.bias_nxt));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ped[0]), "+v"(ped[1]), "+v"(ped[2]), "+v"(pipe.af[0]), "+v"(pipe.af[1]), "+v"(pipe.bias_nxt), "+v"(tbl[0]));
+      if constexpr (OVX) {
+        // rows 0 - 6 and this tile's view-direction set are free again: the inputs of the tile after next (clamped: a tile that
+        // does not exist re-reads this one's, nobody looks at the result)
+        const int t2 = tile + 2 * static_cast<int>(gridDim.x);
+        issue_inputs_flat(t2 < n_tiles ? t2 : tile, vset);
+        const int ln = fresh_lane();
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+          float x[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) x[c] = in_n[t][c] + in_n[t][3 + c] * in_n[t][6];   // plain mul then add (train_utils.py:136)
+          rotate3(x, ln >> 4, xr_n[t]);
+        }
+      }
+      // one gap of one block of the stage: its share of the encoding queue (OVX; nothing otherwise)
+      auto enc_hook = [&](auto b_c, auto w_c) {
+        if constexpr (OVX) {
+          constexpr int b = decltype(b_c)::value, w = decltype(w_c)::value;
+          constexpr int q0 = enc_begin(b, KT_D), cap = enc_cap(b, KT_D);
+          auto one = [&](auto q_c) {
+            constexpr int qq = decltype(q_c)::value;
+            if constexpr (qq < kEncOps) {
+              // (asm operands do not make a lambda capture: everything the statements name is bound to a local first)
+              constexpr int mt = enc_table_slot_at(qq);
+              constexpr int m = enc_slot_of(qq), u = m % 16, tq = m / 16, e = u % 8, k2 = u / 8;
+              constexpr int kind = enc_kind(u, qq - enc_first(m));
+              const unsigned ta = tab_addr_v, sa = stash_addr_v;
+              if constexpr (mt >= 0) {   // the table entry of a later slot: an LDS read older than this block's A-fragment read
+                f32x2& dst = tbl[mt & 1];
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(ta), "n"((mt % 16) * 16));
+              }
+              const float xc = xr_n[tq][u % 3];
+              float& val = ev[e & 1];
+              const f32x2 entry = tbl[m & 1];
+              if constexpr (kind == kEncMul) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(val) : "v"(xc), "v"(entry[0]));
+              else if constexpr (kind == kEncFract) asm volatile("v_fract_f32 %0, %0" : "+v"(val));
+              else if constexpr (kind == kEncAdd) asm volatile("v_add_f32 %0, %0, %1" : "+v"(val) : "v"(entry[1]));
+              else if constexpr (kind == kEncSin) asm volatile("v_sin_f32 %0, %0" : "+v"(val));
+              else if constexpr (kind == kEncSel) {
+                const unsigned long long im = idm[u < 3 ? u : 0];
+                asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(val) : "v"(xc), "s"(im));
+              } else if constexpr (kind == kEncCvt) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const float lo = ev[0], hi = ev[1];
+                unsigned dw;
+                if constexpr (F == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(dw) : "v"(lo), "v"(hi));
+                else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(dw) : "v"(lo), "v"(hi));
+                u32x4 pw = __builtin_bit_cast(u32x4, encp);
+                pw[e / 2] = dw;
+                encp = __builtin_bit_cast(BP8, pw);
+              } else {
+                const BP8 piece = encp;
+                asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(sa), "v"(piece), "n"((tq * KXP + k2) * kPieceBytes));
+              }
+            }
+          };
+          if constexpr (w < 2) one(std::integral_constant<int, q0 + w>{});
+          else if constexpr (w == 2) static_for<cap - 2>([&](auto j_c) { one(std::integral_constant<int, q0 + 2 + decltype(j_c)::value>{}); });
+        }
+      };
       run_stage48x<F, PX, NT / 2, KH, KDP, POS_D, false, 0, 12, 12, (NT - 1) / 2, 1>(pipe, hy, [&](int t, int) { return ped[t]; }, bias_at(bias_tile), 0u, pacc,
           [&](auto nt_c, auto s_c) { hidden_op48<F, true, decltype(nt_c)::value, decltype(s_c)::value>(pacc, bg); },
-          [&](auto s_c) { hidden_op48<F, true, NT - 1, decltype(s_c)::value>(pacc, hy); }, &trk);
+          [&](auto s_c) { hidden_op48<F, true, NT - 1, decltype(s_c)::value>(pacc, hy); }, &trk, enc_hook);
       bias_tile += NT / 2;
       // ---- fc_rgb (models.py:253) ----
       constexpr int POS_R = (POS_D + (NT / 2) * (KH + KDP)) % PX;
@@ -938,6 +1040,8 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
   const bool shipped = d.hidden_size == 128 && d.num_layers == 4 && L.skip_mask == 0u && d.use_viewdirs;
   const bool fixed_ok = std::getenv("DEXNERF_G48_RUNTIME_SHAPE") == nullptr;
 #ifdef DN_EXP_ONLY_PAPER   // experiment builds: only the headline instances are compiled (minutes -> seconds per build)
+  if (paper && p.act == nullptr && p.mode == 0 && std::getenv("DEXNERF_G48_NO_OVERLAP") == nullptr)
+    return precision == DN_PREC_F16 ? launch(mlp_forward48_kernel<256, 2, 8, 0x10u, 1, 0, 2>) : launch(mlp_forward48_kernel<256, 1, 8, 0x10u, 1, 0, 2>);
   if (paper && p.act == nullptr && precision == DN_PREC_F16) return launch(mlp_forward48_kernel<256, 2, 8, 0x10u, 1>);
   if (paper && p.act == nullptr) return launch(mlp_forward48_kernel<256, 1, 8, 0x10u, 1>);
   set_error("mlp_forward48: experiment build (DN_EXP_ONLY_PAPER)");
@@ -964,6 +1068,11 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
     lds += static_cast<size_t>(kG48Waves) * 3 * kG48PointsPerWave * sizeof(float);
     if (precision == DN_PREC_F16) return launch(mlp_forward48_kernel<128, 2, 4, 0u, 1, 0, 1>);
     return launch(mlp_forward48_kernel<128, 1, 4, 0u, 1, 0, 1>);
+  }
+  // the paper network on rays + depths (the render path): tile t + 1's xyz encoding inside tile t's view-direction stage
+  if (paper && fixed_ok && p.mode == 0 && std::getenv("DEXNERF_G48_NO_OVERLAP") == nullptr) {
+    if (precision == DN_PREC_F16) return launch(mlp_forward48_kernel<256, 2, 8, 0x10u, 1, 0, 2>);
+    return launch(mlp_forward48_kernel<256, 1, 8, 0x10u, 1, 0, 2>);
   }
   if (precision == DN_PREC_F16) {
     if (paper && fixed_ok) return launch(mlp_forward48_kernel<256, 2, 8, 0x10u, 1>);

@@ -248,14 +248,62 @@ constexpr int xs_trunk_pos(int i, int nt, int kh, int kxp, unsigned mask) {
   return p;
 }
 
+// ---- in-stage xyz encoding (mlp_fused48.hip, OVLP = 2): the work of a lane's 48 slots (three point groups x 16 slots, pe_value op for
+// op) as a flat queue of single instructions, dealt to the blocks of the view-direction stage behind the pending ops.
+// Slot u of a group: MUL (x f'), FRACT, ADD (phase), SIN, [SEL: slots 0-2, identity columns of lane group 0], [CVT: odd elements, two
+// values -> one dword of the piece], [WRITE: element 7, the finished piece -> LDS stash].
+constexpr int enc_slot_len(int u) { return 4 + (u < 3 ? 1 : 0) + ((u % 8) % 2) + ((u % 8) == 7 ? 1 : 0); }
+constexpr int enc_first(int m) {   // queue position of slot m's first op (m = 16 group + u)
+  int q = 0;
+  for (int i = 0; i < m; ++i) q += enc_slot_len(i % 16);
+  return q;
+}
+constexpr int kEncSlots = 48;
+constexpr int kEncOps = enc_first(kEncSlots);
+constexpr int enc_slot_of(int q) {
+  int m = 0;
+  while (m < kEncSlots && q >= enc_slot_len(m % 16)) { q -= enc_slot_len(m % 16); ++m; }
+  return m;
+}
+enum { kEncMul = 0, kEncFract = 1, kEncAdd = 2, kEncSin = 3, kEncSel = 4, kEncCvt = 5, kEncWrite = 6 };
+constexpr int enc_kind(int u, int idx) {
+  if (idx < 4) return idx;
+  int j = 4;
+  if (u < 3) { if (idx == j) return kEncSel; ++j; }
+  if ((u % 8) % 2) { if (idx == j) return kEncCvt; ++j; }
+  return kEncWrite;
+}
+// a block of a KT-piece tile takes 3 ops (one per MFMA gap, beside the two pending ops of the tile's first six blocks) or 4 (op-free blocks)
+constexpr int enc_cap(int b, int kt) { return (b % kt) >= 6 ? 4 : 3; }
+constexpr int enc_begin(int b, int kt) {
+  int q = 0;
+  for (int i = 0; i < b; ++i) q += enc_cap(i, kt);
+  return q;
+}
+// the table entry of slot m is read kEncLead queue positions ahead of its MUL: more than a block's capacity, so at least one counted
+// wait of the A-fragment pipeline lies in between (it retires every older LDS read); slot 0's is read before the stage
+constexpr int kEncLead = 5;
+constexpr int enc_table_slot_at(int q) {   // the slot whose table read rides at queue position q, or -1
+  for (int m = 1; m < kEncSlots; ++m)
+    if (enc_first(m) - kEncLead == q) return m;
+  return -1;
+}
+
 // One GEMM stage, explicit schedule.  NOPS: ops per tile of THIS stage, run by ops(nt_c, s_c) on `pacc` during the following tile;
 // PX: the barrier period in pieces (Pipe48::xs_period_begin).  PEND_N / PEND_BY: the ops the caller still owes for the previous stage's last tile (pend(s_c)) and the block of this stage's
 // first tile by which they must be done.  On return `pacc` holds the last tile's accumulators and the caller owes ITS NOPS ops.
 // TRK: as run_stage48 (fp16 range tracker on the stage's input pieces), two dwords per instruction, in the op-free blocks.
+// Hook: other work riding in the stage's blocks - hook(block_c, where_c) is called behind the ops of MFMA gap `where` = 0, 1, 2 of
+// block `block` = nt * KT + k, and with where = 3 just BEFORE the block's A-fragment read: an LDS operation issued there is older
+// than that read, so the next block's counted wait (at most ONE younger read in flight) has retired it - no wait of its own.
+struct XsNoHook {
+  template <class B, class W>
+  __device__ __forceinline__ void operator()(B, W) const {}
+};
 template <int F, int PX, int NT_OUT, int KH, int KP, int POS0, bool LAST, int PAD, int NOPS, int PEND_N, int PEND_BY, int TRK = 0, class PipeT, class BH,
-          class BP, class Ops, class Pend>
+          class BP, class Ops, class Pend, class Hook = XsNoHook>
 __device__ __forceinline__ void run_stage48x(PipeT& pipe, const BH& bh, BP&& bp, unsigned bias_addr, unsigned next_addr, f32x4 (&pacc)[3],
-                                             Ops&& ops, Pend&& pend, unsigned* trk = nullptr) {
+                                             Ops&& ops, Pend&& pend, unsigned* trk = nullptr, Hook&& hook = Hook{}) {
   constexpr int PT = 3, KT = KH + KP;
   static_assert(KT >= 2 && KH >= 1, "the bias prefetch distance assumes at least two pieces per tile; a tile's first piece is a hidden piece");
   static_for<NT_OUT>([&](auto nt_c) {
@@ -322,10 +370,12 @@ __device__ __forceinline__ void run_stage48x(PipeT& pipe, const BH& bh, BP&& bp,
           if constexpr (t < 2) run_trk(std::integral_constant<int, kb * TPER + t>{});
           else static_for<(TPER > 2 ? TPER - 2 : 0)>([&](auto j_c) { run_trk(std::integral_constant<int, kb * TPER + 2 + decltype(j_c)::value>{}); });
         }
+        hook(std::integral_constant<int, nt * KT + k>{}, t_c);
       });
       if constexpr (KT - E <= 0 && NTRK > 0 && k == KT - 1)   // no op-free block: the tracker's ops behind the tile's last MFMA
         static_for<NTRK>([&](auto q_c) { run_trk(q_c); });
       pipe.template xs_after_piece<PX, pos>();
+      hook(std::integral_constant<int, nt * KT + k>{}, std::integral_constant<int, 3>{});
       if constexpr (g48_issued<LAST, POS0 + NT_OUT * KT, PAD>(pos + kPrefetch, pos + kPrefetch + 1) == 1) pipe.template prefetch<pos>();
       if constexpr (k == KT - 2) {
         if constexpr (nt + 1 < NT_OUT) pipe.template bias_prefetch<(nt + 1) * 64>(bias_addr);

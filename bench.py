@@ -138,7 +138,9 @@ def kernel_source_sha16():
 def headline_kernel_name(precision):
     """Demangled name of the instance the fine-net launch of the headline configuration runs (what rocprofv3 reports)."""
     if geometry48(precision):
-        return f"mlp_forward48_kernel<256, {2 if precision == 'fp16' else 1}, 8, 16u, 1, 0, 0, 0>"
+        # (rays + depths: the instance that encodes tile t + 1 inside tile t's view-direction stage, unless switched off)
+        ovl = 0 if os.environ.get("DEXNERF_G48_NO_OVERLAP") else 2
+        return f"mlp_forward48_kernel<256, {2 if precision == 'fp16' else 1}, 8, 16u, 1, 0, {ovl}, 0>"
     return "mlp_forward_kernel<256, 10, 4"
 
 

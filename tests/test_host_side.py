@@ -280,12 +280,12 @@ def test_bench_refuses_a_pmc_record_of_another_kernel_or_other_sources(tmp_path,
     for name in bench.KERNEL_SOURCES:
         (csrc / name).write_text("// " + name)
     sha = bench.kernel_source_sha16()
-    good = {"kernel": "void dn::mlp_forward48_kernel<256, 1, 8, 16u, 1, 0, 0, 0>(dn::FwdParams, dn::G48Params)", "source_sha16": sha,
+    good = {"kernel": "void dn::mlp_forward48_kernel<256, 1, 8, 16u, 1, 0, 2, 0>(dn::FwdParams, dn::G48Params)", "source_sha16": sha,
             "derived": {"hbm_bytes_per_launch": 6.4e8, "matrix_pipe_busy_frac": 0.8}}
     (prof / "r04_pmc_fine_net_bf16.json").write_text(json.dumps(good))
     rec = bench.pmc_record("bf16")
     assert rec["hbm_bytes_per_launch"] == 6.4e8 and rec["record"] == "profiles/r04_pmc_fine_net_bf16.json"
-    (prof / "r04_pmc_fine_net_bf16.json").write_text(json.dumps(dict(good, kernel="void dn::mlp_forward48_kernel<256, 2, 8, 16u, 1, 0, 0, 0>(...)")))
+    (prof / "r04_pmc_fine_net_bf16.json").write_text(json.dumps(dict(good, kernel="void dn::mlp_forward48_kernel<256, 2, 8, 16u, 1, 0, 2, 0>(...)")))
     rec = bench.pmc_record("bf16")
     assert "hbm_bytes_per_launch" not in rec and "refused" in rec["record"]
     (prof / "r04_pmc_fine_net_bf16.json").write_text(json.dumps(good))

@@ -234,7 +234,7 @@ def train_rate(models, cfg, ro, rd, ex, ed, n_rays=4096, steps=8, dist=None, pos
     res = {"rays_per_s": world * n_rays / dt, "ms_per_step": dt * 1e3, "rays_per_step_per_gpu": n_rays, "n_gpus": world,
            "hip_graphs_per_step": len(graphed.graphs) if graphed.graphs else 0, "graph_fallback": graphed.fallback_reason,
            "what": "device pixel draw + ray rows + fwd + loss + bwd + Adam (nerf.FusedTrainStep + nerf.FlatAdam under nerf.GraphedTrainStep), " + what_tail}
-    # roofline of the step: HBM-bound by construction - the saved activations and gradients are written
+    # roofline of the step: HBM-bound by construction (HISTORY.md section 4.6) - the saved activations and gradients are written
     # once by the forward / backward chains and read once by the weight-gradient kernel; MFMA rate beside it (3x forward FLOP)
     nbytes = 0
     for m, s in ((models[0], nc), (models[1], nc + nf)):
@@ -656,7 +656,7 @@ def main():
             result["train"] = train_rate(models, cfg, ro, rd, ex, ed)
         if not args.no_train and world == 1 and args.precision == "bf16":
             # the same iteration with the tensors saved for the backward at 16 bits on the 32-point training kernels (what 'bf16' meant up to
-            # round 3; 'bf16' now saves at 8 bits on the 48-point kernels - same forward bits)
+            # round 3; 'bf16' now saves at 8 bits on the 48-point kernels - same forward bits; HISTORY.md section 4.6)
             nerf.set_precision("bf16-s16")
             try:
                 models16, cfg16, _, _, _, _ = build_scene(dev, rank)

@@ -971,7 +971,7 @@ int launch_pack48_pair(const dn_mlp_desc& d, const PackPtrs& a, const PackPtrs& 
 }
 
 // In-kernel compositing is OFF unless DEXNERF_FUSED_COMPOSITE=1 (read per call).  It is bit-identical to the two-kernel path and
-// takes the raw radiance field out of HBM (fine launch of the headline configuration: see DESIGN.md section 4.7f for the PMC bytes),
+// takes the raw radiance field out of HBM (fine launch of the headline configuration: see HISTORY.md section 4.7f for the PMC bytes),
 // but it costs time: a ray is composited by ONE wave with its SIMD to itself - exponentials, divisions and an fp64 scan as one
 // dependency chain - where the standalone kernel hides that latency behind eight waves per SIMD; measured +3 % on a D8/W256
 // render and +26 % on the as-shipped 4 x 128 nets.  The network kernels are not byte-bound, so the bytes saved buy nothing back.

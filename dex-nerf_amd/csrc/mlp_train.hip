@@ -1639,7 +1639,7 @@ static int wg_launch_batch(WgBatch& b, const long long* unit_tiles, bool f32, bo
   const int n_units = b.n_units;
   // (one workgroup per CU.  Two per CU on half the LDS - an instance of the W = 128 layer shapes only, 128 VGPRs - was tried for the
   // as-shipped nets, whose launches are bound by the wait / barrier / LDS round trip of a tile: the tile loop got 13-26 us shorter,
-  // the reduction of twice as many partials 50 us longer - DESIGN.md section 4.6)
+  // the reduction of twice as many partials 50 us longer - HISTORY.md section 4.7c)
   int total_wg = device_cus();
   if (total_wg < n_units) total_wg = n_units;
   long long cost[kWgMaxUnits], cost_sum = 0;

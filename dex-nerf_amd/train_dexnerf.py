@@ -137,6 +137,9 @@ def main(argv=None):
     ap.add_argument("--s8-grad-scale", type=float, default=None,
                     help="bf16: power of two the 8-bit saved layer gradients are scaled by; default 0 = chosen per launch from the "
                          "largest upstream gradient (nerf.set_s8_grad_scale)")
+    ap.add_argument("--atomic-weight-gradients", action="store_true",
+                    help="add the weight-gradient partials with fp32 atomics (no scratch buffer, a few percent faster on small nets) instead "
+                         "of the fixed-order reduction: a run is then no longer reproducible bit for bit")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16-s8", "bf16-s16", "fp32"],
                     help="bf16 (= bf16-s8): bf16 kernels, the tensors saved for the backward at 8 bits; bf16-s16: at 16 bits (nerf.set_precision)")
     ap.add_argument("--validate-every", type=int, default=500)
@@ -190,6 +193,8 @@ def main(argv=None):
     nerf.set_precision(args.precision)
     if args.s8_grad_scale is not None:
         nerf.set_s8_grad_scale(args.s8_grad_scale)
+    from nerf import _ops as _nerf_ops
+    _nerf_ops.set_deterministic_weight_gradients(not args.atomic_weight_gradients)
     s8_warned, s8_saturated_max = False, 0.0
 
     kw = dict(num_layers=args.layers, hidden_size=args.width, skip_connect_every=4, num_encoding_fn_xyz=10,
@@ -373,6 +378,10 @@ def main(argv=None):
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    # process-wide switches this run set go back to the library's defaults (main() is also called as a function: tests, bench.py)
+    if args.s8_grad_scale is not None:
+        nerf.set_s8_grad_scale(0.0)
+    _nerf_ops.set_deterministic_weight_gradients(True)
     return result
 
 

@@ -1,5 +1,5 @@
 // Developer probe (GPU box): lane / byte mapping of gfx950's 8-bit transposing LDS read ds_read_b64_tr_b8, the read an
-// 8-bit weight-gradient kernel would stage its operands with.  LDS byte i holds (i & 255); every lane
+// 8-bit weight-gradient kernel would stage its operands with (HISTORY.md section 4.6b).  LDS byte i holds (i & 255); every lane
 // reads at lane * 8 (the natural lane-linear image) and at a row-major [16 rows][stride] image; the program prints, per lane,
 // the 8 bytes it received.   hipcc --offload-arch=gfx950 -O2 -o tr8_probe tr8_probe.hip && ./tr8_probe
 #include <hip/hip_runtime.h>

@@ -4,7 +4,7 @@ hazard recognizer and waitcnt insertion cannot see - is checked in the instructi
 
   * SGPR-base VMEM (store16_uniform's global_store_dwordx4, Pipe::dma_phase's global_load_lds_dwordx4): >= 5 wait states
     after the v_readfirstlane_b32 that produced the base (round 1 aborted on the GPU box before those were spelled out,
-    DESIGN.md section 4.6);
+    HISTORY.md section 4.6);
   * M0 written one instruction + nop before the LDS-DMA that reads it;
   * no VALU write to a > 8-byte store's data registers in the following wait state (the round-1 data corruption);
   * the explicit LDS read pipeline of mlp_forward48_kernel / mlp_backward48_kernel: nothing names a fragment register between its ds_read and the

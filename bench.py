@@ -121,7 +121,7 @@ def geometry48(precision):
     return precision in ("bf16", "fp16") and os.environ.get("DEXNERF_BF16_GEOM", "") != "32"
 
 
-KERNEL_SOURCES = ("mlp_fused48.hip", "mlp_stage48.h", "mlp_device.h", "mlp_geo48.h")
+KERNEL_SOURCES = ("mlp_fused48.hip", "mlp_fused48_kernel.h", "mlp_stage48.h", "mlp_device.h", "mlp_geo48.h")
 
 
 def kernel_source_sha16():

@@ -26,10 +26,14 @@ for prec in ("bf16", "fp16"):
                 os.environ["DEXNERF_G48_NO_OVERLAP"] = "1"
             else:
                 os.environ.pop("DEXNERF_G48_NO_OVERLAP", None)
-            for rep in range(3):
-                torch.cuda.synchronize(); t0 = time.perf_counter()
+            reps = []
+            for rep in range(12):   # device time of the launch (events on the current stream), median of the last ten
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 out = _ops.run_network_rays(pk, rays, z)
-                torch.cuda.synchronize(); times[mode] = time.perf_counter() - t0
+                e1.record(); torch.cuda.synchronize()
+                reps.append(e0.elapsed_time(e1) * 1e-3)
+            times[mode] = sorted(reps[2:])[5]
             outs[mode] = out
         same = torch.equal(outs["overlap"], outs["plain"])
         ok = ok and same

@@ -48,6 +48,7 @@ static size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255);
 
 struct Workspace {
   float *z_c, *rf_c, *w_c, *z_f, *rf_f, *g_rf;
+  unsigned* absmax_part;   // training: one word per workgroup of the compositing backward (largest |gradient| it stored)
   unsigned* status;   // the last 256 bytes: word 0 = non-finite raw radiance-field values met by this call's compositing
   size_t bytes;
 };
@@ -68,6 +69,7 @@ static Workspace carve(void* base, int64_t n, int nc, int nf, bool train = false
     w.rf_f = take(static_cast<size_t>(n) * (nc + nf) * 4);
   }
   if (train) w.g_rf = take(static_cast<size_t>(n) * (nc + nf) * 4);   // d loss / d raw radiance field, one network at a time
+  if (train) w.absmax_part = reinterpret_cast<unsigned*>(take(static_cast<size_t>((n + 3) / 4)));
   w.status = reinterpret_cast<unsigned*>(take(64));
   w.bytes = off;
   return w;
@@ -209,11 +211,16 @@ extern "C" int dn_render_rays_backward_ws(const dn_mlp_desc* desc_coarse, const 
                   const float* noise, const float* g_rgb, const float* g_depth, const float* g_acc, const void* act,
                   const void* masks, void* grads, float* const* h_dW, float* const* h_db, uint32_t noise_stream) -> int {
     DN_REQUIRE(desc && packed_bwd && act && masks && grads && h_dW && h_db, "dn_render_rays_backward: a network's buffers are missing");
+    // 8-bit saved tensors with the per-launch gradient scale: the compositing backward leaves the largest |gradient| of each of its
+    // workgroups behind, and the network backward reduces those words itself - no pass over g_rf in between (a few thousand words at
+    // most: beyond that the separate reduction kernel is the cheaper one)
+    const int64_t n_parts = (n_rays + 3) / 4;
+    unsigned* parts = (precision == DN_PREC_BF16_S8 && s8_scale_is_per_launch() && n_parts <= 4096) ? w.absmax_part : nullptr;
     if ((rc = volume_render_backward_rng(rf, z, rays + 3, ray_stride, noise, noise_std, white_background, n_rays, samples,
-                                         g_rgb, g_depth, g_acc, nullptr, nullptr, w.g_rf, rng_state, noise_stream, stream)))
+                                         g_rgb, g_depth, g_acc, nullptr, nullptr, w.g_rf, rng_state, noise_stream, stream, parts)))
       return rc;
     const int64_t n_points = n_rays * samples;
-    if ((rc = dn_mlp_backward_data(desc, precision, packed_bwd, w.g_rf, masks, n_points, grads, stream))) return rc;
+    if ((rc = mlp_backward_data_partials(desc, precision, packed_bwd, w.g_rf, masks, n_points, grads, parts, static_cast<int>(parts ? n_parts : 0), stream))) return rc;
     if (pair_wgrad) return 0;   // both networks' weight gradients follow in one launch
     // (one network at a time: the launches are stream-ordered, so the scratch is free again when the second one starts)
     return dn_mlp_weight_grad_all_ws(desc, precision, act, grads, n_points, h_dW, h_db, wg_scratch, wg_scratch_bytes, stream);

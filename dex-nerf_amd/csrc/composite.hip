@@ -34,10 +34,16 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float4* __restrict__ rf, const float* __restrict__ z, const float* __restrict__ rd, int rd_stride,
     const float* __restrict__ noise, float noise_std, int white, int64_t n_rays, int S, const float* __restrict__ g_rgb,
     const float* __restrict__ g_depth, const float* __restrict__ g_acc, const float* __restrict__ g_disp,
-    const float* __restrict__ g_weights, float4* __restrict__ g_rf, RngRef rng) {
+    const float* __restrict__ g_weights, float4* __restrict__ g_rf, RngRef rng, unsigned* __restrict__ absmax_part) {
   const int lane = lane_id();
-  const int64_t ray = static_cast<int64_t>(blockIdx.x) * kRaysPerBlock + (threadIdx.x >> 6);
-  if (ray >= n_rays) return;
+  const int64_t ray_of_wave = static_cast<int64_t>(blockIdx.x) * kRaysPerBlock + (threadIdx.x >> 6);
+  // absmax_part (the 8-bit-saved-tensor training path, api.cpp): this workgroup's largest finite |gradient it stores| goes to
+  // absmax_part[blockIdx.x] - what absmax_kernel (mlp_train48.hip) would otherwise read g_rf again for.  Every workgroup writes its
+  // word (nothing needs zeroing), so a wave without a ray stays for the workgroup's exchange: it works on the last ray and stores nothing.
+  const bool live = ray_of_wave < n_rays;
+  if (!live && absmax_part == nullptr) return;
+  const int64_t ray = live ? ray_of_wave : n_rays - 1;
+  float gmax = 0.0f;
   const float dx = rd[ray * rd_stride + 0], dy = rd[ray * rd_stride + 1], dz = rd[ray * rd_stride + 2];
   const float rd_norm = sqrtf((dx * dx + dy * dy) + dz * dz);
   const float* zr = z + ray * S;
@@ -115,7 +121,27 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
       g.y = w_[c] * gc1 * c1_[c] * (1.0f - c1_[c]);
       g.z = w_[c] * gc2 * c2_[c] * (1.0f - c2_[c]);
       g.w = dsig;
-      g_rf[ray * S + s] = g;
+      if (live) {
+        g_rf[ray * S + s] = g;
+        const float a0 = fabsf(g.x), a1 = fabsf(g.y), a2 = fabsf(g.z), a3 = fabsf(g.w);
+        gmax = (a0 < 3.0e38f) ? fmaxf(gmax, a0) : gmax;   // (a non-finite gradient does not set the scale: absmax_kernel's rule)
+        gmax = (a1 < 3.0e38f) ? fmaxf(gmax, a1) : gmax;
+        gmax = (a2 < 3.0e38f) ? fmaxf(gmax, a2) : gmax;
+        gmax = (a3 < 3.0e38f) ? fmaxf(gmax, a3) : gmax;
+      }
+    }
+  }
+  if (absmax_part != nullptr) {   // (workgroup-uniform)
+    __shared__ float wave_max[kRaysPerBlock];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
+    if (lane == 0) wave_max[threadIdx.x >> 6] = gmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float r = wave_max[0];
+#pragma unroll
+      for (int w = 1; w < kRaysPerBlock; ++w) r = fmaxf(r, wave_max[w]);
+      absmax_part[blockIdx.x] = __float_as_uint(r);
     }
   }
 }
@@ -159,13 +185,13 @@ extern "C" int dn_volume_render_backward(const float* rf, const float* z, const 
                                          const float* g_disp, const float* g_weights, float* g_rf,
                                          dn_stream_t stream) {
   return dn::volume_render_backward_rng(rf, z, rd, rd_stride, noise, noise_std, white_background, n_rays, n_samples, g_rgb, g_depth, g_acc,
-                                        g_disp, g_weights, g_rf, nullptr, 0u, stream);
+                                        g_disp, g_weights, g_rf, nullptr, 0u, stream, nullptr);
 }
 
 int dn::volume_render_backward_rng(const float* rf, const float* z, const float* rd, int rd_stride, const float* noise, float noise_std,
                                    int white_background, int64_t n_rays, int n_samples, const float* g_rgb, const float* g_depth,
                                    const float* g_acc, const float* g_disp, const float* g_weights, float* g_rf,
-                                   const uint32_t* rng_state, uint32_t rng_stream, dn_stream_t stream) {
+                                   const uint32_t* rng_state, uint32_t rng_stream, dn_stream_t stream, unsigned* absmax_part) {
   if (n_rays == 0) return 0;
   DN_REQUIRE(rf && z && rd && g_rf && n_rays >= 0 && n_samples >= 1 && rd_stride >= 3,
              "dn_volume_render_backward: bad arguments");
@@ -178,7 +204,7 @@ int dn::volume_render_backward_rng(const float* rf, const float* z, const float*
 #define DN_LAUNCH_BWD(MC)                                                                                          \
   hipLaunchKernelGGL(composite_bwd_kernel<MC>, dim3(grid), dim3(256), 0, as_stream(stream),                        \
                      reinterpret_cast<const float4*>(rf), z, rd, rd_stride, noise, noise_std, white_background,    \
-                     n_rays, n_samples, g_rgb, g_depth, g_acc, g_disp, g_weights, reinterpret_cast<float4*>(g_rf), RngRef{rng_state, rng_stream})
+                     n_rays, n_samples, g_rgb, g_depth, g_acc, g_disp, g_weights, reinterpret_cast<float4*>(g_rf), RngRef{rng_state, rng_stream}, absmax_part)
   if (chunks <= 1) DN_LAUNCH_BWD(1);
   else if (chunks <= 2) DN_LAUNCH_BWD(2);
   else if (chunks <= 4) DN_LAUNCH_BWD(4);

@@ -56,7 +56,12 @@ int fine_depths_rng(const float* z_coarse, const float* weights, const float* u,
 int volume_render_backward_rng(const float* rf, const float* z, const float* rd, int rd_stride, const float* noise, float noise_std,
                                int white_background, int64_t n_rays, int n_samples, const float* g_rgb, const float* g_depth,
                                const float* g_acc, const float* g_disp, const float* g_weights, float* g_rf,
-                               const uint32_t* rng_state, uint32_t rng_stream, dn_stream_t stream);
+                               const uint32_t* rng_state, uint32_t rng_stream, dn_stream_t stream, unsigned* absmax_part = nullptr);
+// mlp_train.hip: dn_mlp_backward_data with the largest |g_out| already formed by the caller's previous kernel (DN_PREC_BF16_S8 with the
+// per-launch gradient scale): n_partials words whose maximum it is (composite.hip composite_bwd_kernel) - NULL: a launch of its own finds it
+int mlp_backward_data_partials(const dn_mlp_desc* desc, int precision, const void* packed_bwd, const float* g_out, const void* masks,
+                               int64_t n_points, void* grads, const unsigned* partials, int n_partials, dn_stream_t stream);
+bool s8_scale_is_per_launch();   // mlp_train.hip: dn_set_s8_grad_scale(0), the default
 
 #define DN_REQUIRE(cond, ...)     \
   do {                            \

@@ -244,7 +244,7 @@ int launch_pack48(const dn_mlp_desc& d, int precision, const PackPtrs& ptrs, cha
 int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p, const char* region, hipStream_t stream,
                      const CompParams* comp = nullptr, int* composited = nullptr);
 int backward48_entry(const dn_mlp_desc* desc, const void* packed_bwd, const float* g_out, const void* masks, int64_t n_points,
-                     void* grads, float grad_scale, hipStream_t stream);                                  // mlp_train48.hip
+                     void* grads, float grad_scale, hipStream_t stream, const unsigned* partials = nullptr, int n_partials = 0);   // mlp_train48.hip
 int unpack48_entry(const dn_mlp_desc* desc, int which, const void* native, int64_t n_points, int slot, int width, int kind, float* out,
                    int ld_out, int col0, hipStream_t stream);                             // mlp_train48.hip
 int launch_pack48_pair(const dn_mlp_desc& d, const PackPtrs& a, const PackPtrs& b, char* region_a, char* region_b, hipStream_t stream);

@@ -440,6 +440,13 @@ extern "C" int dn_run_network_train(const dn_mlp_desc* desc, int precision, cons
 
 extern "C" int dn_mlp_backward_data(const dn_mlp_desc* desc, int precision, const void* packed_bwd, const float* g_out,
                                     const void* masks, int64_t n_points, void* grads, dn_stream_t stream) {
+  return dn::mlp_backward_data_partials(desc, precision, packed_bwd, g_out, masks, n_points, grads, nullptr, 0, stream);
+}
+
+bool dn::s8_scale_is_per_launch() { return g_s8_grad_scale.load() == 0.0f; }
+
+int dn::mlp_backward_data_partials(const dn_mlp_desc* desc, int precision, const void* packed_bwd, const float* g_out, const void* masks,
+                                   int64_t n_points, void* grads, const unsigned* partials, int n_partials, dn_stream_t stream) {
   const bool s8 = precision == DN_PREC_BF16_S8;
   if (s8) precision = DN_PREC_BF16;
   int rc = validate_desc(desc, precision);
@@ -451,7 +458,7 @@ extern "C" int dn_mlp_backward_data(const dn_mlp_desc* desc, int precision, cons
   if (s8) {   // the 48-point chain (mlp_train48.hip)
     DN_REQUIRE(g48_train_supported(*desc), "dn_mlp_backward_data: no 8-bit-saved-tensor training kernels for this network (see dn_mlp_train_sizes)");
     DN_REQUIRE(n_points < (1LL << 31) - 1024, "dn_mlp_backward_data (8-bit saved tensors): at most 2^31 - 1024 points per call");
-    return backward48_entry(desc, packed_bwd, g_out, masks, n_points, grads, g_s8_grad_scale.load(), as_stream(stream));
+    return backward48_entry(desc, packed_bwd, g_out, masks, n_points, grads, g_s8_grad_scale.load(), as_stream(stream), partials, n_partials);
   }
   NetLayout L;
   build_backward_layout(*desc, precision, &L);

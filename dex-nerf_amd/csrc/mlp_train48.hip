@@ -27,7 +27,9 @@ struct Bwd48Params {
   int grad_units;
   int gslot_dirout, gslot_feat, gslot_trunk0, gslot_layer1, gslot_out;
   float scale;             // the power of two the gradients are multiplied by before they are rounded to e5m2 (auto_scale: unused)
-  int auto_scale;          // pick the scale from the largest |upstream gradient| (block[0], formed by absmax_kernel before this launch)
+  int auto_scale;          // pick the scale from the largest |upstream gradient|: the maximum of the n_partials words at `partials`
+  const unsigned* partials;   // (absmax_kernel's 24 in the record, or the compositing backward's one per workgroup: composite.hip)
+  int n_partials;
   unsigned* block;         // the 256-byte record behind the saved gradients (kS8Block*): statistics + the scale that was used
   // (the saturation bounds +-57344 / scale are formed once at the top of the kernel, as TWO values - a bound negated at its
   // uses has CodeGenPrepare sink a copy of the free fneg to each of the thousands of uses in the unrolled tile pass: ten minutes)
@@ -91,8 +93,10 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
   // same number from the same word; one thread records it for the weight-gradient kernel and the statistics reader.
   float scale = p.scale;
   if (p.auto_scale) {
-    float gmax = 0.0f;   // the partial maxima absmax_kernel left in the record (words kS8BlockPartials ..; unused ones are zero)
-    for (int i = 0; i < kS8BlockPartialCount; ++i) gmax = fmaxf(gmax, __uint_as_float(p.block[kS8BlockPartials + i]));
+    float gmax = 0.0f;   // every wave reduces the partial maxima itself (a few KiB out of L2): lanes stride the words, then a wave maximum
+    for (int i = lane; i < p.n_partials; i += 64) gmax = fmaxf(gmax, __uint_as_float(p.partials[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
     scale = (gmax > 0.0f && gmax < 3.0e38f) ? exp2f(fminf(fmaxf(12.0f - ceilf(log2f(gmax)), -100.0f), 100.0f)) : 65536.0f;
   }
   // (wave-uniform numbers pinned to scalar registers: formed by vector instructions, they would each hold a VGPR for the whole
@@ -487,7 +491,7 @@ using namespace dn;
 // The C entry points (dn_mlp_backward_data, dn_mlp_pack_backward, dn_mlp_train_sizes, ...) live in mlp_train.hip and dispatch here
 // for DN_PREC_BF16_S8.
 int dn::backward48_entry(const dn_mlp_desc* desc, const void* packed_bwd, const float* g_out, const void* masks, int64_t n_points,
-                         void* grads, float grad_scale, hipStream_t stream) {
+                         void* grads, float grad_scale, hipStream_t stream, const unsigned* partials, int n_partials) {
   TrainLayout48 t;
   build_train_layout48(*desc, &t);
   Bwd48Params p{};
@@ -506,10 +510,12 @@ int dn::backward48_entry(const dn_mlp_desc* desc, const void* packed_bwd, const 
   p.block = reinterpret_cast<unsigned*>(static_cast<char*>(grads) + g48_padded_records(n_points) * 2 * t.grad_units * kPieceBytes);
   p.auto_scale = grad_scale == 0.0f ? 1 : 0;
   p.scale = p.auto_scale ? 65536.0f : grad_scale;
-  if (p.auto_scale) {
+  p.partials = partials; p.n_partials = n_partials;
+  if (p.auto_scale && partials == nullptr) {
     hipLaunchKernelGGL(absmax_kernel, dim3(kS8BlockPartialCount), dim3(1024), 0, stream, reinterpret_cast<const float4*>(g_out),
                        static_cast<long long>(n_points), p.block);
     if (int rc = check_launch("s8 absmax")) return rc;
+    p.partials = p.block + kS8BlockPartials; p.n_partials = kS8BlockPartialCount;
   }
   return launch_backward48(*desc, p, stream);
 }

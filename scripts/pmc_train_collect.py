@@ -6,7 +6,7 @@ from collections import defaultdict
 mode = sys.argv[1]
 KERNELS = ("mlp_forward_kernel", "mlp_backward_kernel", "mlp_forward48_kernel", "mlp_backward48_kernel", "weight_grad_batch_kernel")
 out = {"mode": mode, "kernels": {}}
-for name in ("mfma", "sqA", "sqB"):
+for name in ("fetch", "write", "mfma", "sqA", "sqB"):
     cc = glob.glob(f"gpurun_out/pmc_train_{mode}_{name}/*/*counter_collection.csv")
     tr = glob.glob(f"gpurun_out/pmc_train_{mode}_{name}/*/*kernel_trace.csv")
     if not cc or not tr:
@@ -37,6 +37,14 @@ for k, rec in out["kernels"].items():
         w = rec["SQ_WAVE_CYCLES"]
         for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VALU"):
             d[c + "/wave_cycles"] = rec[c] / w
+    if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
+        # MI355X_MICROARCH.md: FETCH_SIZE in KiB, one half of the bytes of wide coalesced reads on gfx950 (x 2); WRITE_SIZE in KiB
+        d["hbm_read_bytes"] = 2.0 * rec["FETCH_SIZE"] * 1024.0
+        d["hbm_write_bytes"] = rec["WRITE_SIZE"] * 1024.0
+        ms = rec.get("kernel_ms_mfma") or rec.get("kernel_ms_fetch")
+        d["hbm_tb_per_s"] = (d["hbm_read_bytes"] + d["hbm_write_bytes"]) / (ms * 1e-3) / 1e12
+        d["hbm_frac_of_8tb"] = d["hbm_tb_per_s"] / 8.0
+        d["hbm_frac_of_measured_copy_6p29tb"] = d["hbm_tb_per_s"] / 6.29
     if "SQ_LDS_IDX_ACTIVE" in rec and rec["SQ_LDS_IDX_ACTIVE"]:
         d["lds_bank_conflict/lds_idx_active"] = rec["SQ_LDS_BANK_CONFLICT"] / rec["SQ_LDS_IDX_ACTIVE"]
 json.dump(out, open(f"gpurun_out/pmc_train_{mode}.json", "w"), indent=1)

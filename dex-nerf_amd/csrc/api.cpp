@@ -1,5 +1,6 @@
 // Library-level entry points: error string, ABI version, and the fused predict_and_render_radiance
 // forward (reference nerf/train_utils.py:92-202) sequenced on one stream from the per-stage kernels.
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -215,7 +216,9 @@ extern "C" int dn_render_rays_backward_ws(const dn_mlp_desc* desc_coarse, const 
     // workgroups behind, and the network backward reduces those words itself - no pass over g_rf in between (a few thousand words at
     // most: beyond that the separate reduction kernel is the cheaper one)
     const int64_t n_parts = (n_rays + 3) / 4;
-    unsigned* parts = (precision == DN_PREC_BF16_S8 && s8_scale_is_per_launch() && n_parts <= 4096) ? w.absmax_part : nullptr;
+    // (DEXNERF_S8_ABSMAX_KERNEL=1, read per call: the separate reduction kernel regardless - the A/B of tests/test_hip_parity.py)
+    unsigned* parts = (precision == DN_PREC_BF16_S8 && s8_scale_is_per_launch() && n_parts <= 4096 && std::getenv("DEXNERF_S8_ABSMAX_KERNEL") == nullptr)
+                          ? w.absmax_part : nullptr;
     if ((rc = volume_render_backward_rng(rf, z, rays + 3, ray_stride, noise, noise_std, white_background, n_rays, samples,
                                          g_rgb, g_depth, g_acc, nullptr, nullptr, w.g_rf, rng_state, noise_stream, stream, parts)))
       return rc;

@@ -2321,6 +2321,38 @@ def test_s8_statistics_and_per_launch_scale_under_a_sum_reduced_loss(dev):
         nerf.set_precision("fp32")
 
 
+def test_gradient_scale_from_the_compositing_backward_equals_the_separate_reduction(dev, tmp_path, monkeypatch):
+    """'bf16' training takes the e5m2 scale of every backward launch from its largest upstream gradient.  Inside dn_render_rays_backward
+    that maximum comes from the compositing backward (one word per workgroup, reduced by the network backward: csrc/composite.hip,
+    mlp_train48.hip) instead of a reduction launch of its own (absmax_kernel, what a stand-alone dn_mlp_backward_data runs;
+    DEXNERF_S8_ABSMAX_KERNEL=1 forces it here too).  A maximum has no order: both ways must pick the same power of two, so two runs of
+    the training driver - ragged ray count: the last workgroup of the compositing backward has idle waves - end in identical weights."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "dex-nerf_amd"))
+    import nerf
+    import train_dexnerf
+    try:
+        base = ["--size", "32", "--views", "6", "--num-random-rays", "509", "--layers", "4", "--width", "128", "--validate-every", "0",
+                "--quiet", "--precision", "bf16", "--iters", "60", "--no-hip-graph"]
+        paths = [os.path.join(str(tmp_path), f"scale_{k}.ckpt") for k in range(2)]
+        scales = []
+        for k, path in enumerate(paths):
+            if k == 1:
+                monkeypatch.setenv("DEXNERF_S8_ABSMAX_KERNEL", "1")
+            train_dexnerf.main(base + ["--save", path])
+            st = nerf.s8_grad_stats()
+            assert st is not None and st["saturated"] == 0.0 and all(0.0 < v and np.log2(v) == round(np.log2(v)) for v in st["scale"]), st
+            scales.append(st["scale"])
+        monkeypatch.delenv("DEXNERF_S8_ABSMAX_KERNEL")
+        assert scales[0] == scales[1], scales
+        a, b = (torch.load(p, map_location="cpu") for p in paths)
+        for key in ("model_coarse_state_dict", "model_fine_state_dict"):
+            for name in a[key]:
+                assert torch.equal(a[key][name], b[key][name]), (key, name)
+    finally:
+        nerf.set_precision("fp32")
+
+
 def test_llff_capture_renders_through_the_ndc_branch(dev, tmp_path):
     """SURVEY 8f N2 + S2b end to end: a forward-facing capture on disk in the LLFF layout -> nerf.load_llff_data -> 4-argument
     get_ray_bundle (camera-to-world convention) -> run_one_iter_of_nerf with dataset.no_ndc = False (near 0, far 1: the LLFF

@@ -389,11 +389,11 @@ __device__ __forceinline__ void run_stage48x(PipeT& pipe, const BH& bh, BP&& bp,
 }
 
 // rows 4g..4g+3 of output tile NT -> elements (NT & 1) * 4 .. + 3 of B piece NT / 2 (g48_hidden_col)
-// CLAMP (training forward with 8-bit saved tensors): the stage output is limited to e4m3's range (448) before it is rounded
-// to 16 bits, so that the saved byte can be formed straight from the 16-bit pairs (v_cvt_scalef32_pk_fp8_bf16 does not
-// saturate: an overflow converts to NaN - measured, scripts/micro/cvt_scale_probe.hip).  No activation of a trainable net is
-// anywhere near 448: below it the bits are the inference kernel's.
-template <int F, bool RELU, int NT, bool CLAMP = false, class BO>
+// (The training forward with 8-bit saved tensors runs the same two instructions per dword as the inference kernels: its saved e4m3
+// bytes are formed from the 16-bit pairs by v_cvt_scalef32_pk_fp8_bf16, which SATURATES at 448 when MODE.FP16_OVFL is set - measured,
+// scripts/micro/cvt_sat_probe.hip; in the default mode an overflow converts to NaN, and rounds 2-3 clamped every stage output with a
+// v_med3_f32 per element first: a third of this epilogue's instructions.  mlp_fused48_kernel.h sets the bit for SAVE instances.)
+template <int F, bool RELU, int NT, class BO>
 __device__ __forceinline__ void emit48(const f32x4& acc, BO& bo) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef typename Prec<F>::Elem e16x2 __attribute__((ext_vector_type(2)));
@@ -409,14 +409,8 @@ __device__ __forceinline__ void emit48(const f32x4& acc, BO& bo) {
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
     f32x2 f = {acc[2 * d], acc[2 * d + 1]};
-    if constexpr (CLAMP) {
-      // one v_med3_f32 per element: ReLU and the upper limit at once (fminf / fmaxf each cost a canonicalising v_max_f32 more)
-      constexpr float lo = RELU ? 0.0f : -kE4m3Max;
-      f[0] = __builtin_amdgcn_fmed3f(f[0], lo, kE4m3Max);
-      f[1] = __builtin_amdgcn_fmed3f(f[1], lo, kE4m3Max);
-    }
     e16x2 v = __builtin_convertvector(f, e16x2);  // one packed convert
-    if constexpr (RELU && !CLAMP) {  // a negative bf16 / fp16 is a negative int16 (mlp_device.h make_piece)
+    if constexpr (RELU) {  // a negative bf16 / fp16 is a negative int16 (mlp_device.h make_piece)
       s16x2 bits = __builtin_bit_cast(s16x2, v);
       const s16x2 zero = {0, 0};
       bits = __builtin_elementwise_max(bits, zero);

@@ -40,7 +40,7 @@ constexpr int kBwd48WaveLds = 8 * kPieceBytes;   // per wave: 2 output-gradient 
 // masked gradient tile -> elements of the next stage's B piece + (every fourth tile) one saved unit
 //   mw: this group's mask dwords (lo: tiles 0-7, hi: tiles 8-15), bit layout of mlp_geo48.h
 template <int NT, class BO>
-__device__ __forceinline__ void emit_grad48(const f32x4& acc, unsigned mw_lo, unsigned mw_hi, float lo, float hi, BO& bo) {
+__device__ __forceinline__ void emit_grad48(const f32x4& acc, unsigned mw_lo, unsigned mw_hi, BO& bo) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -48,8 +48,9 @@ __device__ __forceinline__ void emit_grad48(const f32x4& acc, unsigned mw_lo, un
   const unsigned word = (NT >> 3) ? mw_hi : mw_lo;
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
-    // saturate in fp32, before the 16-bit rounding: the saved e5m2 byte is then formed straight from the 16-bit pair
-    const f32x2 f = {__builtin_amdgcn_fmed3f(acc[2 * d], lo, hi), __builtin_amdgcn_fmed3f(acc[2 * d + 1], lo, hi)};
+    // (no clamp: the saved e5m2 byte is formed straight from the 16-bit pair by a conversion that saturates - MODE.FP16_OVFL, set at
+    // the top of the kernel; rounds 2-3 spent a v_med3_f32 per element here)
+    const f32x2 f = {acc[2 * d], acc[2 * d + 1]};
     const unsigned pair = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
     // mask bits of registers 2d / 2d+1 sit at position p and p + 16: (bits & 0x00010001) = a 0 / 1 factor per 16-bit half, applied
     // with ONE packed 16-bit multiply (x * 1 = x, x * 0 = 0 on the bit pattern; as a multiply by 0xFFFF and an AND it was two)
@@ -104,7 +105,10 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
   auto uniform_f = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
   scale = uniform_f(scale);
   const float inv_scale = uniform_f(1.0f / scale);
-  const float clamp_hi = uniform_f(kE5m2Max * inv_scale), clamp_lo = uniform_f(-kE5m2Max * inv_scale);
+  // the e5m2 conversions of the saved gradients saturate at +-57344 (MODE.FP16_OVFL, bit 23: an overflow becomes the largest finite
+  // value instead of inf - scripts/micro/cvt_sat_probe.hip; nothing else this bf16 kernel runs reads the bit): the gradient that flows
+  // down the chain is not clamped, only its saved byte is, and the statistics count those bytes as before
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
   if (blockIdx.x == 0 && threadIdx.x == 0) p.block[kS8BlockScale] = __float_as_uint(scale);
   // (the statistics words of the record are zeroed here for the weight-gradient kernel - the next launch on the stream - which
   // counts saturated / floor-level stores while it reads the gradients anyway)
@@ -175,9 +179,8 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
         const f32x4 v = *reinterpret_cast<const f32x4*>(wbuf + g_slot * kPieceBytes + (t * 16 + j) * 16);
         const int pt = tile * PPG + wave * PPW + t * 16 + j;
         const bool live = (lane < 16) && (pt < n_points);   // padding points (clamped copies in the forward) contribute nothing
-        // (saturated like every other gradient of the chain: the custom pieces are stored as e5m2 too)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) gv[t][c] = live ? __builtin_amdgcn_fmed3f(v[c], clamp_lo, clamp_hi) : 0.0f;
+        for (int c = 0; c < 4; ++c) gv[t][c] = live ? v[c] : 0.0f;
       }
     }
     // Start of stage q: fetch this stage's mask words from their LDS slot, then stage what will be needed two stages on (same
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
     };
     auto emit_to = [&](auto nt_c, auto t_c, const f32x4& acc, auto& bout, int gslot) {
       constexpr int nt = decltype(nt_c)::value, t = decltype(t_c)::value;
-      emit_grad48<nt>(acc, mw[t][0], mw[t][1], clamp_lo, clamp_hi, bout[t]);
+      emit_grad48<nt>(acc, mw[t][0], mw[t][1], bout[t]);
       if constexpr (nt % 4 == 3) save_unit(t_c, gslot + nt / 4, bout[t][nt / 2 - 1], bout[t][nt / 2]);
     };
 

@@ -135,6 +135,18 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+def kernel_isa_sha16(precision):
+    """sha256 (first 16 hex digits) of the instruction stream of the headline kernel instance in the library this process loads
+    (scripts/codeobj.py: code objects out of the .so, llvm-objdump): the identity of the kernel BINARY.  None without the LLVM tools."""
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts"))
+        import codeobj
+        lib = os.environ.get("DEXNERF_HIP_LIB") or codeobj.DEFAULT_LIB
+        return codeobj.kernel_isa_sha16(headline_kernel_name(precision) + "(", lib)
+    except Exception:  # noqa: BLE001 - informational: the source hash below still guards the record
+        return None
+
+
 def headline_kernel_name(precision):
     """Demangled name of the instance the fine-net launch of the headline configuration runs (what rocprofv3 reports)."""
     if geometry48(precision):
@@ -148,7 +160,8 @@ def pmc_record(precision):
     """The committed rocprofv3 --pmc passes on this exact launch (scripts/pmc_fine_net.sh -> profiles/r0N_pmc_fine_net_<type>.json:
     FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes, FETCH_SIZE doubled per the gfx950 correction of
     MI355X_MICROARCH.md).  bench.py itself cannot run the profiler.  A record is used only if it names the kernel instance this run
-    times AND was collected on the kernel sources of this tree; otherwise `traffic` is null and `traffic_record` says why."""
+    times AND was collected on this kernel binary (or, failing that check, these kernel sources); otherwise `traffic` is null and
+    `traffic_record` says why."""
     want = headline_kernel_name(precision)
     for rnd in ("r04", "r03", "r02"):
         path = os.path.join(REPO, "profiles", f"{rnd}_pmc_fine_net_{precision}.json")
@@ -158,10 +171,17 @@ def pmc_record(precision):
         kernel = doc.get("kernel", "")
         if want not in kernel.replace("dn::", ""):
             return {"record": f"profiles/{os.path.basename(path)} refused: it profiles `{kernel[:80]}`, this run times `{want}`"}
-        if doc.get("source_sha16") != kernel_source_sha16():
+        # the record must belong to the kernel this run times: the same instruction stream (the record's isa_sha16 against the loaded
+        # library's - survives comments and refactors, not a moved instruction), or, where either side lacks it, the same sources
+        isa_here = kernel_isa_sha16(precision) if doc.get("isa_sha16") else None
+        if isa_here is not None:
+            if doc["isa_sha16"] != isa_here:
+                return {"record": f"profiles/{os.path.basename(path)} refused: collected on kernel binary {doc['isa_sha16']}, this library holds {isa_here}"}
+        elif doc.get("source_sha16") != kernel_source_sha16():
             return {"record": f"profiles/{os.path.basename(path)} refused: collected on kernel sources {doc.get('source_sha16')}, this tree has {kernel_source_sha16()}"}
         rec = dict(doc.get("derived", {}))
         rec["record"] = "profiles/" + os.path.basename(path)
+        rec["record_tied_by"] = "isa_sha16" if isa_here is not None else "source_sha16"
         return rec
     return {"record": "no committed PMC record for this precision"}
 

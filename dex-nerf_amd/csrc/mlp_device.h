@@ -101,17 +101,22 @@ struct FwdParams {
 // (counted vmcnt, never 0 in the loop); phase p+4 is issued into the slot phase p-1 just vacated.
 // Extra VMEM ops (input DMAs, the output store) are younger or older than the DMAs a wait must cover and,
 // because VMEM ops retire in order, can only make a counted wait stricter, never weaker.
-// Two classes, one source: the 48-point kernels' translation units (mlp_stage48.h sets DN_PIPE_ASM_READS / _LEADER_DMA /
-// _SCALAR_STATE before this header) get Pipe48 - other members, other methods - the 32-point kernels' units get Pipe.  They
-// never share a name: the same class name with two layouts in two translation units of one library would be an ODR violation
-// that only happens to work because device code is compiled per unit.
-#if defined(DN_PIPE_ASM_READS) || defined(DN_PIPE_LEADER_DMA) || defined(DN_PIPE_SCALAR_STATE)
-#define DN_PIPE_CLASS Pipe48
-#else
-#define DN_PIPE_CLASS Pipe
-#endif
-template <int WAVES>
-struct DN_PIPE_CLASS {
+// One class, two geometries.  The geometry type says which form of the pipeline a kernel family runs:
+//   ASM_READS     the A-fragment / bias LDS reads and their COUNTED waits are opaque asm statements (below)
+//   LEADER_DMA    waves 0-3 fetch the whole weight stream, four pieces each per phase; waves 4-7 issue MFMAs only (mlp_stage48.h)
+//   SCALAR_STATE  the wave-uniform ring bookkeeping is pinned to SGPRs
+//   PREFETCH      depth of the A-fragment FIFO (= the translation unit's kPrefetch)
+// PipeGeo32 (here): the 32-points-per-wave kernels of mlp_fused.hip / mlp_train.hip; PipeGeo48 (mlp_stage48.h): the 48-point kernels.
+// Members only one form uses cost nothing (a Pipe lives in registers; unused fields are never materialised); member functions of a
+// class template are instantiated only where they are called.
+template <bool ASM_READS_, bool LEADER_DMA_, bool SCALAR_STATE_, int PREFETCH_>
+struct PipeGeometry {
+  static constexpr bool ASM_READS = ASM_READS_, LEADER_DMA = LEADER_DMA_, SCALAR_STATE = SCALAR_STATE_;
+  static constexpr int PREFETCH = PREFETCH_;
+};
+template <int WAVES, class G>
+struct PipeT {
+  static_assert(G::PREFETCH == kPrefetch, "the FIFO depth of a geometry is its translation unit's kPrefetch");
   static constexpr int PER_WAVE = kPhasePieces / WAVES;
   char* ring;           // LDS
   unsigned ring_addr;   // its 32-bit LDS byte address (for M0)
@@ -125,8 +130,7 @@ struct DN_PIPE_CLASS {
   const char* rd_nxt;
   unsigned lane16;
   f32x4 af[kPrefetch];  // A-fragment FIFO: af[pos % kPrefetch] holds piece `pos` when it is consumed
-#ifdef DN_PIPE_ASM_READS
-  // Explicit LDS read pipeline (mlp_fused48.hip).  hipcc's own waitcnt insertion turns a depth-2 software pipeline of
+  // ---- ASM_READS: explicit LDS read pipeline (mlp_fused48.hip).  hipcc's own waitcnt insertion turns a depth-2 software pipeline of
   // ds_read_b128 into "issue the read for piece p+2, then s_waitcnt lgkmcnt(0)": every other piece, and every tile's bias
   // read, exposed a full LDS round trip in front of the MFMAs (r02 PMC: waves parked in s_waitcnt 39 % of their cycles).
   // Here the reads and their COUNTED waits are opaque asm statements: a consumer waits with lgkmcnt(N), N = the number of
@@ -168,7 +172,6 @@ struct DN_PIPE_CLASS {
 #endif
   unsigned slot_cur_base;      // (scalar) LDS byte address of the slot of the NEXT phase (becomes rda_cur at phase_begin)
   f32x4 bias_nxt;              // bias rows of the NEXT 16-row tile, read two pieces ahead of its first MFMA
-#endif
 #ifdef DN_EXP_REGSTAGE
   f32x4 stage[PER_WAVE];
   unsigned stage_dst;
@@ -233,33 +236,33 @@ struct DN_PIPE_CLASS {
 #else
     const unsigned who = wave;
 #endif
-#ifdef DN_PIPE_LEADER_DMA
-    // waves 0-3 fetch the whole phase, four pieces each (two right after the barrier, two at mid-phase); waves 4-7 none
-    pend_src = q_issue + who * (2 * PER_WAVE * kPieceBytes);
-    pend_dst = slot_wr * kSlotBytes + who * (2 * PER_WAVE * kPieceBytes);
-#else
-    pend_src = q_issue + who * (PER_WAVE * kPieceBytes);
-    pend_dst = slot_wr * kSlotBytes + who * (PER_WAVE * kPieceBytes);
-#endif
+    if constexpr (G::LEADER_DMA) {
+      // waves 0-3 fetch the whole phase, four pieces each (two right after the barrier, two at mid-phase); waves 4-7 none
+      pend_src = q_issue + who * (2 * PER_WAVE * kPieceBytes);
+      pend_dst = slot_wr * kSlotBytes + who * (2 * PER_WAVE * kPieceBytes);
+    } else {
+      pend_src = q_issue + who * (PER_WAVE * kPieceBytes);
+      pend_dst = slot_wr * kSlotBytes + who * (PER_WAVE * kPieceBytes);
+    }
     q_issue += kSlotBytes;
     if (q_issue >= total_bytes) q_issue = 0;
     slot_wr = (slot_wr + 1 == kRingPhases) ? 0 : slot_wr + 1;
-#ifdef DN_PIPE_SCALAR_STATE  // pin the (wave-uniform) ring state to SGPRs: hipcc otherwise keeps it in ~8 VGPRs (mlp_fused48.hip: 8 -> 0 spills)
-    q_issue = __builtin_amdgcn_readfirstlane(q_issue);
-    slot_wr = __builtin_amdgcn_readfirstlane(slot_wr);
-    pend_src = __builtin_amdgcn_readfirstlane(pend_src);
-    pend_dst = __builtin_amdgcn_readfirstlane(pend_dst);
-#endif
+    if constexpr (G::SCALAR_STATE) {  // pin the (wave-uniform) ring state to SGPRs: hipcc otherwise keeps it in ~8 VGPRs (mlp_fused48.hip: 8 -> 0 spills)
+      q_issue = __builtin_amdgcn_readfirstlane(q_issue);
+      slot_wr = __builtin_amdgcn_readfirstlane(slot_wr);
+      pend_src = __builtin_amdgcn_readfirstlane(pend_src);
+      pend_dst = __builtin_amdgcn_readfirstlane(pend_dst);
+    }
   }
 
   __device__ __forceinline__ void issue_phase() {  // prologue only
     advance_issue();
-#ifdef DN_PIPE_LEADER_DMA
-    dma_phase(pend_src, pend_dst, wave < 4 ? 1u : 0u);
-    dma_phase(pend_src + PER_WAVE * kPieceBytes, pend_dst + PER_WAVE * kPieceBytes, wave < 4 ? 1u : 0u);
-#else
-    dma_phase(pend_src, pend_dst, 1u);
-#endif
+    if constexpr (G::LEADER_DMA) {
+      dma_phase(pend_src, pend_dst, wave < 4 ? 1u : 0u);
+      dma_phase(pend_src + PER_WAVE * kPieceBytes, pend_dst + PER_WAVE * kPieceBytes, wave < 4 ? 1u : 0u);
+    } else {
+      dma_phase(pend_src, pend_dst, 1u);
+    }
   }
 
   // Called at every 16-piece boundary of the (compile-time laid out) consumption sequence.
@@ -281,36 +284,38 @@ struct DN_PIPE_CLASS {
     if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
 #endif
-#elif defined(DN_PIPE_ASM_READS)
-    // No LDS wait here: every read of the slot being recycled (phase p-1) was waited for by the take() in front of its
-    // MFMAs, which precede this point in program order; the reads still in flight belong to phases p and p+1.
-    static_assert(PER_WAVE == 2, "the asm-read pipeline is the 8-wave geometry");
-#ifdef DN_PIPE_LEADER_DMA
-#define DN_PHASE_VMCNT "8"   // a fetching wave has four DMAs per phase: two younger phases stay in flight
 #else
-#define DN_PHASE_VMCNT "4"
+#ifdef DN_STAMP   // (diagnostic builds of the 48-point kernels)
+    unsigned st0 = 0, st1 = 0, st2 = 0;
 #endif
+    if constexpr (G::ASM_READS) {
+      // No LDS wait here: every read of the slot being recycled (phase p-1) was waited for by the take() in front of its
+      // MFMAs, which precede this point in program order; the reads still in flight belong to phases p and p+1.
+      static_assert(!G::ASM_READS || PER_WAVE == 2, "the asm-read pipeline is the 8-wave geometry");
 #if defined(DN_STAMP) && DN_STAMP == 2   // light mode: only the top-of-tile time (two stamps per pass)
-    if (st_top_pending) { st_top += stamp() - st_last; st_top_pending = 0; ++st_n; }
+      if (st_top_pending) { st_top += stamp() - st_last; st_top_pending = 0; ++st_n; }
 #elif defined(DN_STAMP) && DN_STAMP == 4   // stage mode: the top-of-tile ends at the first phase boundary of a pass
-    if (st_top_pending) { const unsigned t = stamp(); st_top += t - st_last; st_last = t; st_top_pending = 0; ++st_n; }
+      if (st_top_pending) { const unsigned t = stamp(); st_top += t - st_last; st_last = t; st_top_pending = 0; ++st_n; }
 #elif defined(DN_STAMP) && DN_STAMP == 3   // barrier mode: arrival / release of every phase barrier (two stamps per phase)
-    const unsigned st0 = stamp();
-    if (st_top_pending) { st_top += st0 - st_last; st_top_pending = 0; }
-    else if (st_n) st_seg += st0 - st_prev;
+      st0 = stamp();
+      if (st_top_pending) { st_top += st0 - st_last; st_top_pending = 0; }
+      else if (st_n) st_seg += st0 - st_prev;
 #elif defined(DN_STAMP)
-    const unsigned st0 = stamp();
-    if (st_top_pending) { st_top += st0 - st_last; st_top_pending = 0; }
-    else if (st_n) { st_seg += st0 - st_prev; st_sub[3] += st0 - st_last; }
+      st0 = stamp();
+      if (st_top_pending) { st_top += st0 - st_last; st_top_pending = 0; }
+      else if (st_n) { st_seg += st0 - st_prev; st_sub[3] += st0 - st_last; }
 #endif
-    asm volatile("s_waitcnt vmcnt(" DN_PHASE_VMCNT ")" ::: "memory");
+      // a fetching wave of the LEADER_DMA form has four DMAs per phase, otherwise every wave two: two younger phases stay in flight
+      if constexpr (G::LEADER_DMA) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #if defined(DN_STAMP) && DN_STAMP == 1
-    const unsigned st1 = stamp();
-    st_vm += st1 - st0;
+      st1 = stamp();
+      st_vm += st1 - st0;
 #endif
-#else
-    if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    } else {
+      if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    }
 #endif
 #ifdef DN_EXP_REGSTAGE
     // experiment: weights through registers (global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA
@@ -331,8 +336,8 @@ struct DN_PIPE_CLASS {
 #ifndef DN_EXP_NOBARRIER   // timing experiment only (UNSAFE: no cross-wave ordering of ring slots)
     __builtin_amdgcn_s_barrier();
 #endif
-#if defined(DN_STAMP) && DN_STAMP == 1 && defined(DN_PIPE_ASM_READS)
-    const unsigned st2 = stamp();
+#if defined(DN_STAMP) && DN_STAMP == 1
+    st2 = stamp();
     st_bar += st2 - st1;
 #elif defined(DN_STAMP) && DN_STAMP == 3
     st_prev = stamp();
@@ -345,7 +350,7 @@ struct DN_PIPE_CLASS {
 #endif
     advance_issue();
     dma_phase(pend_src, pend_dst, (WAVES == 4 || wave < 4) ? 1u : 0u);
-#if defined(DN_STAMP) && DN_STAMP == 1 && defined(DN_PIPE_ASM_READS)
+#if defined(DN_STAMP) && DN_STAMP == 1
     st_prev = stamp();
     st_dma += st_prev - st2;
     st_last = st_prev;
@@ -353,13 +358,13 @@ struct DN_PIPE_CLASS {
 #endif
 #endif
     slot_nxt = (slot_nxt + 1 == kRingPhases) ? 0 : slot_nxt + 1;
-#ifdef DN_PIPE_ASM_READS
-    rda_cur = slot_cur_base + lane16;
-    slot_cur_base = __builtin_amdgcn_readfirstlane(ring_addr + slot_nxt * kSlotBytes);   // now the NEXT phase's slot
-#else
-    rd_cur = rd_nxt;
-    rd_nxt = ring + slot_nxt * kSlotBytes + lane16;
-#endif
+    if constexpr (G::ASM_READS) {
+      rda_cur = slot_cur_base + lane16;
+      slot_cur_base = __builtin_amdgcn_readfirstlane(ring_addr + slot_nxt * kSlotBytes);   // now the NEXT phase's slot
+    } else {
+      rd_cur = rd_nxt;
+      rd_nxt = ring + slot_nxt * kSlotBytes + lane16;
+    }
   }
 
   __device__ __forceinline__ void mid_phase() {
@@ -370,11 +375,8 @@ struct DN_PIPE_CLASS {
 #if defined(DN_STAMP) && DN_STAMP == 1
     const unsigned m0 = stamp();
 #endif
-#ifdef DN_PIPE_LEADER_DMA
-    if constexpr (WAVES == 8) dma_phase(pend_src + PER_WAVE * kPieceBytes, pend_dst + PER_WAVE * kPieceBytes, wave < 4 ? 1u : 0u);
-#else
-    if constexpr (WAVES == 8) dma_phase(pend_src, pend_dst, wave >= 4 ? 1u : 0u);
-#endif
+    if constexpr (WAVES == 8 && G::LEADER_DMA) dma_phase(pend_src + PER_WAVE * kPieceBytes, pend_dst + PER_WAVE * kPieceBytes, wave < 4 ? 1u : 0u);
+    else if constexpr (WAVES == 8) dma_phase(pend_src, pend_dst, wave >= 4 ? 1u : 0u);
 #if defined(DN_STAMP) && DN_STAMP == 1
     const unsigned m1 = stamp();
     st_dma += m1 - m0;
@@ -384,7 +386,7 @@ struct DN_PIPE_CLASS {
 #endif
   }
 
-#if defined(DN_PIPE_ASM_READS) && defined(DN_PIPE_LEADER_DMA)
+  // (the forms below - two-phase barrier period, spread fetch - are the ASM_READS + LEADER_DMA geometry's: nothing else calls them)
   // ---- one workgroup barrier per TWO phases (PH = 32: the fixed-shape W = 256 instance, where the parity of a phase is a
   // compile-time position).  The barrier is the one cost of the ring that cannot be overlapped: the SIMD partners do not share
   // the matrix pipe fairly, the older wave parks ~630 cycles at every barrier and the younger one then runs alone.
@@ -417,8 +419,6 @@ struct DN_PIPE_CLASS {
       dma_phase(pend_src + PER_WAVE * kPieceBytes, pend_dst + PER_WAVE * kPieceBytes, wave < 4 ? 1u : 0u);
     }
   }
-#endif
-#if defined(DN_PIPE_ASM_READS) && defined(DN_PIPE_LEADER_DMA)
   // ---- the same two-phase period with the fetch SPREAD over the period's first half (explicit-schedule instances, run_stage48x).
   // What a weight DMA costs its wave is the queue in front of the CU's one address path: behind the barrier the four fetching waves
   // used to issue four 1 KiB loads each at once (and four more at mid-phase) - ~80 cycles per load for the issuing wave, measured
@@ -486,25 +486,17 @@ struct DN_PIPE_CLASS {
   __device__ __forceinline__ void xs_after_piece() {
     if constexpr ((POS % PERIOD) < PERIOD / 2) xs_dma_step<PERIOD, POS % PERIOD>();
   }
-#endif
   // phase boundary / mid-phase hooks at position POS of a stream whose barrier period is PH pieces (16, or 32: see above)
   template <int PH, int POS>
   __device__ __forceinline__ void at_position() {
+    static_assert(PH == kPhasePieces || (G::ASM_READS && G::LEADER_DMA), "the two-phase barrier period is the 48-point geometry's");
     if constexpr (POS % kPhasePieces == 0) {
-#if defined(DN_PIPE_ASM_READS) && defined(DN_PIPE_LEADER_DMA)
       if constexpr (PH == 2 * kPhasePieces) phase_begin2<(POS % PH) == 0>();
       else phase_begin();
-#else
-      phase_begin();
-#endif
     }
     if constexpr (POS % kPhasePieces == kPhasePieces / 2) {
-#if defined(DN_PIPE_ASM_READS) && defined(DN_PIPE_LEADER_DMA)
       if constexpr (PH == 2 * kPhasePieces) mid_phase2<(POS % PH) == kPhasePieces / 2>();
       else mid_phase();
-#else
-      mid_phase();
-#endif
     }
   }
 
@@ -516,20 +508,13 @@ struct DN_PIPE_CLASS {
       constexpr int pos = POS + decltype(i_c)::value;
       static_assert(pos % kPhasePieces != 0 || decltype(i_c)::value == 0, "padding never crosses a phase");
       if constexpr (pos % kPhasePieces == kPhasePieces / 2) at_position<PH, pos>();
-#ifdef DN_PIPE_ASM_READS
-      // only the last kPrefetch skipped positions fetch pieces that will be consumed (the first pieces of the next pass);
+      // ASM_READS: only the last kPrefetch skipped positions fetch pieces that will be consumed (the first pieces of the next pass);
       // with fewer padding pieces than FIFO entries the stage before has already fetched the rest (run_stage48, PAD)
-      if constexpr (decltype(i_c)::value >= N - kPrefetch) prefetch<pos>();
-#else
-      prefetch<pos>();
-#endif
+      if constexpr (!G::ASM_READS || decltype(i_c)::value >= N - kPrefetch) prefetch<pos>();
     });
-#ifdef DN_PIPE_ASM_READS
     settle<BIAS>();
-#endif
   }
 
-#if defined(DN_PIPE_ASM_READS) && defined(DN_PIPE_LEADER_DMA)
   // the same for the explicit-schedule pass: the fetch steps of the skipped positions still happen
   template <int PERIOD, int POS, int N>
   __device__ __forceinline__ void skip_xs() {
@@ -542,28 +527,27 @@ struct DN_PIPE_CLASS {
     });
     settle<true>();
   }
-#endif
 
   // after consuming piece POS (position within the 16-piece phase), read piece POS + kPrefetch into its FIFO slot
   template <int POS>
   __device__ __forceinline__ void prefetch() {
     constexpr int q = (POS % kPhasePieces) + kPrefetch;
-#ifdef DN_PIPE_ASM_READS
-    const unsigned base = (q < kPhasePieces) ? rda_cur : slot_cur_base + lane16;
+    if constexpr (G::ASM_READS) {
+      const unsigned base = (q < kPhasePieces) ? rda_cur : slot_cur_base + lane16;
 #ifdef DN_EXP_NOREAD   // timing experiment only: no A-fragment traffic (the FIFO keeps whatever it held)
-    asm volatile("; no read %1" : "+v"(af[POS % kPrefetch]) : "v"(base));
+      asm volatile("; no read %1" : "+v"(af[POS % kPrefetch]) : "v"(base));
 #else
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[POS % kPrefetch]) : "v"(base), "n"((q % kPhasePieces) * kPieceBytes));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[POS % kPrefetch]) : "v"(base), "n"((q % kPhasePieces) * kPieceBytes));
 #endif
-#else
-    const char* base = (q < kPhasePieces) ? rd_cur : rd_nxt;
+    } else {
+      const char* base = (q < kPhasePieces) ? rd_cur : rd_nxt;
 #ifndef DN_EXP_NOREAD
-    af[POS % kPrefetch] = *reinterpret_cast<const f32x4*>(base + (q % kPhasePieces) * kPieceBytes);
+      af[POS % kPrefetch] = *reinterpret_cast<const f32x4*>(base + (q % kPhasePieces) * kPieceBytes);
 #endif
-#endif
+    }
   }
 
-#ifdef DN_PIPE_ASM_READS
+  // ---- ASM_READS: the explicit reads and their counted waits ----
   // prologue: FIFO entry E (piece E of the first phase) from the slot rda_nxt points at
   template <int E>
   __device__ __forceinline__ void prologue_read() {
@@ -595,6 +579,7 @@ struct DN_PIPE_CLASS {
   // and after the padding pieces: one exposed LDS round trip per stage (12 per 1184 pieces).
   template <bool BIAS = true>   // BIAS = false: a stream without bias rows (the backward chain) - bias_nxt is not a live register
   __device__ __forceinline__ void settle() {
+    if constexpr (!G::ASM_READS) return;   // (compiler-issued reads: the compiler places its own waits)
 #ifdef DN_EXP_NOSETTLE   // timing experiment only (UNSAFE: phi copies may read fragments in flight)
     return;
 #endif
@@ -607,11 +592,15 @@ struct DN_PIPE_CLASS {
     else if constexpr (kPrefetch == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(bias_nxt));
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[kPrefetch - 1]), "+v"(bias_nxt));
   }
-#else
-  template <bool BIAS = true>
-  __device__ __forceinline__ void settle() {}
-#endif
 };
+// the 32-points-per-wave kernels (mlp_fused.hip, mlp_train.hip): compiler-issued reads, every wave fetches, FIFO of kPrefetch = 4
+#ifdef DN_PREFETCH_SET_BY_KERNEL_SOURCE   // (a 48-point translation unit: kPrefetch is that geometry's; this alias is not instantiated there)
+using PipeGeo32 = PipeGeometry<false, false, false, 4>;
+#else
+using PipeGeo32 = PipeGeometry<false, false, false, kPrefetch>;
+#endif
+template <int WAVES>
+using Pipe = PipeT<WAVES, PipeGeo32>;
 
 template <int BF16>
 __device__ __forceinline__ f32x16 mma_piece(f32x16 acc, f32x4 a_raw, typename Prec<BF16>::BPiece b) {

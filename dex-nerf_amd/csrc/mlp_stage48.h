@@ -26,6 +26,22 @@
 
 namespace dn {
 
+// the weight pipeline of this geometry (mlp_device.h PipeT): explicit LDS reads, waves 0-3 fetch, scalar ring state, FIFO of 2 - each
+// switchable by the ablation hooks above
+#ifdef DN_PIPE_ASM_READS
+constexpr bool kG48AsmReads = true;
+#else
+constexpr bool kG48AsmReads = false;
+#endif
+#ifdef DN_PIPE_LEADER_DMA
+constexpr bool kG48LeaderDma = true;
+#else
+constexpr bool kG48LeaderDma = false;
+#endif
+using PipeGeo48 = PipeGeometry<kG48AsmReads, kG48LeaderDma, true, kPrefetch>;
+template <int WAVES>
+using Pipe48 = PipeT<WAVES, PipeGeo48>;
+
 // F = 1: bf16, 2: fp16 (Prec<F> of mlp_device.h): same MFMA rate and layouts
 template <int F>
 __device__ __forceinline__ f32x4 mfma48(typename Prec<F>::BPiece a, typename Prec<F>::BPiece b, f32x4 c) {

@@ -54,6 +54,28 @@ def disassemble(co):
     return funcs
 
 
+def kernel_isa_sha16(want, lib=None):
+    """sha256 (first 16 hex digits) of the instruction stream of the one kernel of `lib` whose demangled name contains `want`: the
+    identity of a kernel BINARY - unchanged by comments, refactors and edits to other kernels, changed by anything that moves an
+    instruction.  bench.py ties a committed PMC record to the library it runs with this.  None when the tools or the kernel are missing."""
+    import hashlib
+    import tempfile
+    lib = lib or DEFAULT_LIB
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            for co in extract_code_objects(lib, d):
+                table = subprocess.check_output([f"{LLVM}/llvm-objdump", "-t", co], text=True, stderr=subprocess.DEVNULL)
+                syms = subprocess.run(["c++filt"], input=table, text=True, capture_output=True, check=True).stdout
+                if want not in syms.replace("dn::", ""):
+                    continue
+                hits = [ins for name, ins in disassemble(co).items() if want in name.replace("dn::", "")]
+                if len(hits) == 1:
+                    return hashlib.sha256("\n".join(hits[0]).encode()).hexdigest()[:16]
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return None
+
+
 if __name__ == "__main__":
     import tempfile
     lib = sys.argv[1] if len(sys.argv) > 1 and os.path.exists(sys.argv[1]) else DEFAULT_LIB

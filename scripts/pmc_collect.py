@@ -77,6 +77,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 try:
     import bench
     out["source_sha16"] = bench.kernel_source_sha16()
+    prec = "fp16" if ", 2, 8, 16u" in out.get("kernel", "") else "bf16"
+    out["isa_sha16"] = bench.kernel_isa_sha16(prec)   # the kernel binary's identity (None without the LLVM tools)
 except Exception as exc:  # noqa: BLE001
     out["source_sha16"] = f"unavailable: {exc}"
 json.dump(out, open(f"gpurun_out/pmc_{tag}.json", "w"), indent=1)

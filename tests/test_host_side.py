@@ -293,6 +293,16 @@ def test_bench_refuses_a_pmc_record_of_another_kernel_or_other_sources(tmp_path,
     rec = bench.pmc_record("bf16")
     assert "hbm_bytes_per_launch" not in rec and "refused" in rec["record"]
     assert bench.pmc_record("fp16")["record"].startswith("no committed")
+    # a record that carries the kernel BINARY's identity (scripts/codeobj.py kernel_isa_sha16: the instruction stream of the instance in
+    # the built library) is tied by that - it survives edited sources (comments, refactors), not another instruction stream
+    isa = bench.kernel_isa_sha16("bf16")
+    if isa is not None:   # (the LLVM tools of the ROCm image)
+        (prof / "r04_pmc_fine_net_bf16.json").write_text(json.dumps(dict(good, isa_sha16=isa)))
+        rec = bench.pmc_record("bf16")   # (the sources were edited above: the source hash no longer matches)
+        assert rec.get("hbm_bytes_per_launch") == 6.4e8 and rec["record_tied_by"] == "isa_sha16", rec
+        (prof / "r04_pmc_fine_net_bf16.json").write_text(json.dumps(dict(good, isa_sha16="0" * 16)))
+        rec = bench.pmc_record("bf16")
+        assert "hbm_bytes_per_launch" not in rec and "kernel binary" in rec["record"], rec
 
 
 def test_run_reference_launcher_resolves_the_builds_package(tmp_path):

@@ -28,6 +28,7 @@ extern template __global__ void mlp_forward48_kernel<128, 2, 4, 0u, 1, 0, 1>(Fwd
 extern template __global__ void mlp_forward48_kernel<128, 1, 4, 0u, 1, 0, 0, 1>(FwdParams, G48Params);
 extern template __global__ void mlp_forward48_kernel<128, 2, 4, 0u, 1, 0, 0, 1>(FwdParams, G48Params);
 extern template __global__ void mlp_forward48_kernel<128, 1, 4, 0u, 1, 2>(FwdParams, G48Params);
+extern template __global__ void mlp_forward48_kernel<128, 1, 4, 0u, 1, 3>(FwdParams, G48Params);
 extern template __global__ void mlp_forward48_kernel<128, 1, 0, 0u, 0, 2>(FwdParams, G48Params);
 
 // ---- pack: nn.Linear tensors -> bias rows + encoding tables + 16x32 A pieces -----------------------------------
@@ -183,7 +184,7 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
   size_t lds = g48_lds_bytes(L);
   if (lds > 160 * 1024) { set_error("mlp_forward48: %zu bytes of LDS", lds); return DN_E_UNSUPPORTED; }
   const int cus = device_cus();
-  const long long grid = p.n_tiles < cus ? p.n_tiles : cus;
+  long long grid = p.n_tiles < cus ? p.n_tiles : cus;
   auto launch = [&](auto kern) -> int {
     if (int rc = ensure_big_lds(reinterpret_cast<const void*>(kern))) return rc;
 #ifdef DN_STAMP   // diagnostic build: synchronous, allocates, prints - never part of the shipped library
@@ -240,6 +241,11 @@ int launch_forward48(const dn_mlp_desc& d, int precision, const FwdParams& p_in,
 #else
   if (p.act != nullptr) {   // training forward (DN_PREC_BF16_S8): saved units + mask words
     if (precision != DN_PREC_BF16 || !p.save8) { set_error("mlp_forward48(train): the 48-point training forward is the bf16 / 8-bit-saved-tensor mode"); return DN_E_UNSUPPORTED; }
+    if (g48_two_group_shape(d) && g48_train_groups(p.n_points, cus) == 2) {   // small launch: 256-point tiles (mlp_geo48.h; the backward asks the same question)
+      p.n_tiles = (p.n_points + 255) / 256;
+      grid = p.n_tiles < cus ? p.n_tiles : cus;
+      return paper ? launch(mlp_forward48_kernel<256, 1, 8, 0x10u, 1, 3>) : launch(mlp_forward48_kernel<128, 1, 4, 0u, 1, 3>);
+    }
     if (paper && fixed_ok) return launch(mlp_forward48_kernel<256, 1, 8, 0x10u, 1, 2>);
     if (shipped && fixed_ok) return launch(mlp_forward48_kernel<128, 1, 4, 0u, 1, 2>);
     return d.hidden_size == 256 ? launch(mlp_forward48_kernel<256, 1, 0, 0u, 0, 2>) : launch(mlp_forward48_kernel<128, 1, 0, 0u, 0, 2>);

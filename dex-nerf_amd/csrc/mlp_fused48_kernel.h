@@ -53,7 +53,12 @@ __device__ __forceinline__ void rotate3(const float (&x)[3], int g, float (&xr)[
 // barrier one wave per finished ray runs the body of composite_fwd_kernel on them (composite_body.h: the same code, the same bits).
 template <int W, int F, int DC = 0, unsigned MASKC = 0, int VIEWC = 0, int SAVE = 0, int OVLP = 0, int COMP = 0>
 __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdParams p, G48Params q) {
-  static_assert(SAVE == 0 || (SAVE == 2 && F == 1), "saved tensors: the 8-bit layout, bf16 arithmetic");
+  // SAVE = 3: the same training forward on TWO point groups per wave (32 points, 256 per workgroup tile) - for launches so small that
+  // 384-point tiles leave compute units idle or make a short last round (mlp_geo48.h g48_train_groups: a 1024-ray step of the as-shipped
+  // nets is 171 + 342 tiles on 256 units).  Same per-point arithmetic, same saved units (the layout is by 16-point group), mask words
+  // per wave tile as before with the third group's words absent; the backward instance of the same width reads them back.
+  static_assert(SAVE == 0 || ((SAVE == 2 || SAVE == 3) && F == 1), "saved tensors: the 8-bit layout, bf16 arithmetic");
+  static_assert(SAVE != 3 || (OVLP == 0 && COMP == 0 && DC > 0), "two point groups per wave: the fixed-shape training forward");
   static_assert(COMP == 0 || (SAVE == 0 && OVLP == 0 && DC > 0), "in-kernel compositing: a render instance whose xyz stash is free at the end of a pass");
   constexpr bool OVL = OVLP == 1;
   static_assert(!OVL || (DC >= 3 && MASKC == 0u && VIEWC != 0 && SAVE == 0 && W == 128),
@@ -84,13 +89,13 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
 #endif
   using BP8 = typename Prec<F>::BPiece;
   using Elem = typename Prec<F>::Elem;
-  constexpr int PT = 3;
+  constexpr int PT = SAVE == 3 ? 2 : 3;   // point groups per wave
   constexpr int NT = W / 16;
   constexpr int KH = W / 32;
   constexpr int KXP = kG48XyzPieces, KDP = kG48DirPieces;
   constexpr int WAVES = kG48Waves;
-  constexpr int PPW = kG48PointsPerWave;
-  constexpr int PPG = kG48PointsPerWg;
+  constexpr int PPW = 16 * PT;             // = kG48PointsPerWave but for SAVE = 3
+  constexpr int PPG = kG48Waves * PPW;
 
   // training forward: the 8-bit conversions of the saved units saturate (MODE.FP16_OVFL, bit 23: an e4m3 overflow becomes 448 instead of
   // NaN - scripts/micro/cvt_sat_probe.hip), so the stage outputs need no clamp; nothing else this bf16 instance runs reads the bit
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, vset = (VSETS == 2 ? vset ^ 1 : (vset == 2 ? 0 : vset + 1))) {
     // training forward: this wave's three point groups' saved-unit bases and its mask words' (s8-48 layout, mlp_geo48.h) - wave-
     // uniform, kept in scalar registers for the tile; every store adds a small offset (store16_uniform_at)
-    const char* act_grp[PT] = {nullptr, nullptr, nullptr};
+    const char* act_grp[PT] = {};
     const char* mask_base = nullptr;
     if constexpr (SAVE != 0) {
       const long long wt = static_cast<long long>(tile) * WAVES + wave;
@@ -355,7 +360,8 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
     auto mask_store = [&](int stage) {
       if constexpr (SAVE != 0) {
         store16_uniform_at(mask_base, static_cast<unsigned>(stage) * (2 * kPieceBytes), pipe.lane16, make_uint4(maskw[0][0], maskw[0][1], maskw[1][0], maskw[1][1]));
-        store16_uniform_at(mask_base, static_cast<unsigned>(stage) * (2 * kPieceBytes) + kPieceBytes, pipe.lane16, make_uint4(maskw[2][0], maskw[2][1], 0u, 0u));
+        if constexpr (PT == 3)
+          store16_uniform_at(mask_base, static_cast<unsigned>(stage) * (2 * kPieceBytes) + kPieceBytes, pipe.lane16, make_uint4(maskw[PT - 1][0], maskw[PT - 1][1], 0u, 0u));
       }
     };
     constexpr int KHU = KH / 2;   // units of a hidden vector

@@ -12,6 +12,7 @@ template __global__ void mlp_forward48_kernel<128, 2, 4, 0u, 1, 0, 1>(FwdParams,
 template __global__ void mlp_forward48_kernel<128, 1, 4, 0u, 1, 0, 0, 1>(FwdParams, G48Params);
 template __global__ void mlp_forward48_kernel<128, 2, 4, 0u, 1, 0, 0, 1>(FwdParams, G48Params);
 template __global__ void mlp_forward48_kernel<128, 1, 4, 0u, 1, 2>(FwdParams, G48Params);
+template __global__ void mlp_forward48_kernel<128, 1, 4, 0u, 1, 3>(FwdParams, G48Params);
 template __global__ void mlp_forward48_kernel<128, 1, 0, 0u, 0, 2>(FwdParams, G48Params);
 
 }  // namespace dn

@@ -188,9 +188,40 @@ inline void build_train_layout48(const dn_mlp_desc& d, TrainLayout48* t) {
   t->grad_units = g;
 }
 
-// 32-point records the buffers of an n_points launch hold (whole 384-point workgroup tiles)
+// 32-point records the buffers of an n_points launch hold: whole workgroup tiles of whichever training tile shape pads further - 384
+// points (three point groups per wave) or 256 (two: g48_train_groups)
 inline long long g48_padded_records(long long n_points) {
-  return (n_points + kG48PointsPerWg - 1) / kG48PointsPerWg * (kG48PointsPerWg / 32);
+  const long long r3 = (n_points + 383) / 384 * 12, r2 = (n_points + 255) / 256 * 8;
+  return r3 > r2 ? r3 : r2;
+}
+// wave tiles (one 2 KiB mask slot per masked stage each) the mask buffer of an n_points launch must hold: the 256-point tiling has the most
+inline long long g48_mask_wave_tiles(long long n_points) {
+  return (n_points + 255) / 256 * kG48Waves;
+}
+// Point groups per wave the TRAINING forward / backward of an n_points launch run on `cus` compute units: 3 (48 points per wave, 384 per
+// workgroup tile - one pass of the weight stream serves the most points) unless 256-point tiles finish the launch in clearly fewer
+// tile-rounds x points: launches of a few hundred tiles, where 384-point tiles leave units idle or make a short last round (a 1024-ray
+// step of the as-shipped nets: 171 and 342 tiles on 256 units -> 256 and 512 tiles of two thirds the work).  Forward and backward
+// of a launch must agree (the mask words are per wave tile): both call this.  DEXNERF_G48_TRAIN_GROUPS=2|3 (read per call) forces one.
+// (only the two fixed shapes have two-group instances: the paper network and the as-shipped 4 x 128 nets, as mlp_fused48.hip knows them)
+inline bool g48_two_group_shape(const dn_mlp_desc& d) {
+  NetLayout L;
+  build_layout48(d, &L);
+  const bool paper = d.hidden_size == 256 && d.num_layers == 8 && L.skip_mask == 0x10u && d.use_viewdirs;
+  const bool shipped = d.hidden_size == 128 && d.num_layers == 4 && L.skip_mask == 0u && d.use_viewdirs;
+  return (paper || shipped) && std::getenv("DEXNERF_G48_RUNTIME_SHAPE") == nullptr;
+}
+inline int g48_train_groups(long long n_points, int cus) {
+  if (const char* e = std::getenv("DEXNERF_G48_TRAIN_GROUPS")) {
+    const int v = std::atoi(e);
+    if (v == 2 || v == 3) return v;
+  }
+  if (cus < 1) cus = 1;
+  const long long t3 = (n_points + 383) / 384, t2 = (n_points + 255) / 256;
+  const long long c3 = (t3 + cus - 1) / cus * 3, c2 = (t2 + cus - 1) / cus * 2;
+  // (a 256-point pass streams the same weights as a 384-point one and costs more than two thirds of it: measured on the D8/W256 step,
+  //  the 262,144-point coarse launch - 4 rounds against 3, a ratio of 8 / 9 - gains nothing; the as-shipped step's launches - 2 / 3 - a quarter)
+  return c2 * 100 <= c3 * 75 ? 2 : 3;
 }
 
 // Which networks train in the 48-point geometry (DN_PREC_BF16_S8): W = 128 needs whole 64-feature units for layers_dir.0's

@@ -22,6 +22,7 @@
 // waves 4-7 issue MFMAs only.
 #define DN_PIPE_LEADER_DMA 1
 #endif
+#include <type_traits>
 #include "mlp_geo48.h"
 
 namespace dn {
@@ -74,7 +75,8 @@ template <int F, int NT_OUT, int KH, int KP, int POS0, bool LAST = false, bool S
           bool BIAS = true, class PipeT, class BH, class BP, class Emit>
 __device__ __forceinline__ void run_stage48(PipeT& pipe, const BH& bh, BP&& bp, unsigned bias_addr, unsigned next_addr, Emit&& emit,
                                             unsigned* trk = nullptr) {
-  constexpr int PT = 3, KT = KH + KP;
+  constexpr int PT = static_cast<int>(std::extent<BH, 0>::value), KT = KH + KP;   // point groups per wave: 3 (2: the small-launch training instances)
+  static_assert(PT == 2 || PT == 3, "bh is [point groups][pieces]");
   static_assert(KT >= 2 || !BIAS, "the bias prefetch distance assumes at least two pieces per tile");
   static_for<NT_OUT>([&](auto nt_c) {
     constexpr int nt = decltype(nt_c)::value;

@@ -321,7 +321,7 @@ extern "C" int dn_mlp_train_sizes(const dn_mlp_desc* desc, int precision, int64_
     build_train_layout48(*desc, &t8);
     const size_t records = static_cast<size_t>(g48_padded_records(n_points));
     *act_bytes = records * 2 * t8.act_units * kPieceBytes;
-    *mask_bytes = records / (kG48PointsPerWg / 32) * kG48Waves * t8.mask_stages * 2 * kPieceBytes;
+    *mask_bytes = static_cast<size_t>(g48_mask_wave_tiles(n_points)) * t8.mask_stages * 2 * kPieceBytes;
     *grad_bytes = records * 2 * t8.grad_units * kPieceBytes + kS8BlockBytes;   // + the statistics / scale record (mlp_geo48.h)
     return 0;
   }

@@ -64,20 +64,23 @@ __device__ __forceinline__ void emit_grad48(const f32x4& acc, unsigned mw_lo, un
 
 // W: hidden width; DC > 0: depth fixed at compile time (with VIEWC the view-direction branch) - the tile pass is straight-line
 // code, one settle at its end (mlp_fused48.hip); DC = 0: run-time depth / branch, one settle per stage.
-template <int W, int DC = 0, int VIEWC = 0>
+// PTC: point groups per wave - 3 (48 points, 384 per workgroup tile), or 2 for the small launches the forward ran on 256-point
+// tiles (mlp_fused48_kernel.h SAVE = 3; mlp_geo48.h g48_train_groups): the mask words are per wave tile, so the two must agree.
+template <int W, int DC = 0, int VIEWC = 0, int PTC = 3>
 __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48Params p) {
+  static_assert(PTC == 3 || (PTC == 2 && DC > 0), "two point groups per wave: fixed-shape instances");
   constexpr int F = 1;
   constexpr bool FIXED = DC > 0;
   constexpr bool ST = !FIXED;
   constexpr int PH = kPhasePieces;   // (the two-phase barrier form waits with vmcnt(0): with this kernel's stores in the queue that would be for HBM)
   using BP8 = bf16x8;
-  constexpr int PT = 3;
+  constexpr int PT = PTC;
   constexpr int NT = W / 16;
   constexpr int KH = W / 32;
   constexpr int KHU = KH / 2;
   constexpr int WAVES = kG48Waves;
-  constexpr int PPW = kG48PointsPerWave;
-  constexpr int PPG = kG48PointsPerWg;
+  constexpr int PPW = 16 * PT;
+  constexpr int PPG = kG48Waves * PPW;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -194,7 +197,8 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
         const uint4 w0 = *reinterpret_cast<const uint4*>(slot);
         const uint2 w1 = *reinterpret_cast<const uint2*>(slot + kPieceBytes);
         const unsigned all = (q < n_masks) ? 0u : ~0u;   // the last stage has no mask
-        mw[0][0] = w0.x | all; mw[0][1] = w0.y | all; mw[1][0] = w0.z | all; mw[1][1] = w0.w | all; mw[2][0] = w1.x | all; mw[2][1] = w1.y | all;
+        mw[0][0] = w0.x | all; mw[0][1] = w0.y | all; mw[1][0] = w0.z | all; mw[1][1] = w0.w | all;
+        if constexpr (PT == 3) { mw[PT - 1][0] = w1.x | all; mw[PT - 1][1] = w1.y | all; }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const int r = q + 2;
@@ -466,12 +470,21 @@ int launch_backward48(const dn_mlp_desc& d, Bwd48Params p, hipStream_t stream) {
   p.n_tiles = static_cast<int>((p.n_points + kG48PointsPerWg - 1) / kG48PointsPerWg);
   const size_t lds = static_cast<size_t>(kRingBytes) + kG48Waves * kBwd48WaveLds;
   const int cus = device_cus();
-  const int grid = p.n_tiles < cus ? p.n_tiles : cus;
+  int grid = p.n_tiles < cus ? p.n_tiles : cus;
   auto launch = [&](auto kern) -> int {
     if (int rc = ensure_big_lds(reinterpret_cast<const void*>(kern))) return rc;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(kG48Waves * 64), lds, stream, p);
     return check_launch("mlp_backward48");
   };
+  // a small launch whose forward ran on 256-point tiles (two point groups per wave: mlp_geo48.h - the same question, the same answer)
+  if (g48_two_group_shape(d) && g48_train_groups(p.n_points, cus) == 2) {
+    p.n_tiles = static_cast<int>((p.n_points + 255) / 256);
+    grid = p.n_tiles < cus ? p.n_tiles : cus;
+#ifndef DN_T48_ONLY128
+    if (d.hidden_size == 256) return launch(mlp_backward48_kernel<256, 8, 1, 2>);
+#endif
+    return launch(mlp_backward48_kernel<128, 4, 1, 2>);
+  }
   const bool paper = d.hidden_size == 256 && d.num_layers == 8 && d.use_viewdirs;
   const bool shipped = d.hidden_size == 128 && d.num_layers == 4 && d.use_viewdirs;
   const bool fixed_ok = std::getenv("DEXNERF_G48_RUNTIME_SHAPE") == nullptr;

@@ -73,7 +73,7 @@ def test_explicit_lds_read_pipeline_is_not_touched_in_flight(kernels):
         # the pipeline is really the explicit one: counted waits dominate, the hot loop has no lgkmcnt(0) after a fresh read
         counted = sum(1 for line in ins if line.startswith("s_waitcnt lgkmcnt(1)") or line.startswith("s_waitcnt lgkmcnt(2)"))
         assert counted > 150, (name, counted)
-    assert seen == 24   # forward: 2 widths x {fixed, run-time shape} x {bf16, fp16, bf16 training} + the overlapped-encoding instances of the as-shipped and the paper nets x {bf16, fp16} + the self-compositing fixed-shape instances (2 widths x {bf16, fp16}); backward: 2 widths x {fixed, run-time}
+    assert seen == 28   # forward: 2 widths x {fixed, run-time shape} x {bf16, fp16, bf16 training} + the overlapped-encoding instances of the as-shipped and the paper nets x {bf16, fp16} + the self-compositing fixed-shape instances (2 widths x {bf16, fp16}) + the two-point-group training instances (2 widths); backward: 2 widths x {fixed, run-time, fixed on two point groups}
 
 
 def test_mfma_results_are_read_after_their_wait_states(kernels):

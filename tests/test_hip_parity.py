@@ -2188,10 +2188,60 @@ def test_s8_training_kernels_in_the_48_point_geometry(dev, depth, width, viewdir
         nerf.set_precision("fp32")
 
 
+@pytest.mark.parametrize("depth,width", [(8, 256), (4, 128)])
+def test_s8_training_kernels_on_two_point_groups_per_wave_equal_the_three_group_ones(dev, depth, width, monkeypatch):
+    """Small training launches of the two fixed shapes run 256-point workgroup tiles (two 16-point groups per wave) instead of 384-point
+    ones (csrc/mlp_geo48.h g48_train_groups: fewer idle compute units, no short last round).  Same per-point arithmetic, the same saved
+    units at the same addresses (the layout is by group), other mask-word addresses (per wave tile) that forward and backward agree on:
+    radiance field, saved activations, saved gradients and weight gradients must be IDENTICAL to the three-group instances' - forced
+    either way with DEXNERF_G48_TRAIN_GROUPS - on a ragged point count; and the rule itself must pick what it documents."""
+    import nerf
+    from nerf import _hip, _ops
+    nerf.set_precision("bf16")
+    try:
+        torch.manual_seed(11)
+        m = nerf.models.FlexibleNeRFModel(num_layers=depth, hidden_size=width, skip_connect_every=4, num_encoding_fn_xyz=10,
+                                          num_encoding_fn_dir=4, use_viewdirs=True).to(dev)
+        pk = m.packed()
+        S8 = _hip.PREC_BF16_S8
+        _ops.pack_backward(pk, [x.weight for x in m.linear_modules()], S8)
+        shapes = [tuple(x.weight.shape) for x in m.linear_modules()]
+        for n_rays, s in ((37, 53), (1024, 64), (700, 129)):
+            n = n_rays * s
+            g = torch.Generator(device=dev).manual_seed(n)
+            pts = torch.rand(n, 3, device=dev, generator=g) * 2 - 1
+            vd = torch.nn.functional.normalize(torch.randn(n_rays, 3, device=dev, generator=g), dim=-1)
+            g_out = torch.randn(n, 4, device=dev, generator=g) * 1e-4
+            res = {}
+            for groups in ("2", "3"):
+                monkeypatch.setenv("DEXNERF_G48_TRAIN_GROUPS", groups)
+                out, act, masks = _ops.run_network_train(pk, pts, vd, s, prec=S8)
+                grads = _ops.mlp_backward_data(pk, g_out, masks, n, prec=S8)
+                wg = _ops.mlp_weight_grad_all(pk, act, grads, n, shapes, prec=S8)
+                rec = 2 * 1024 * ((n + 31) // 32)    # bytes of one unit slot over the records that hold real points
+                res[groups] = (out, act, grads, wg, rec)
+            monkeypatch.delenv("DEXNERF_G48_TRAIN_GROUPS")
+            (o2, a2, g2, w2, _), (o3, a3, g3, w3, _) = res["2"], res["3"]
+            assert torch.equal(o2, o3), (n_rays, s)
+            # saved units: identical wherever a real point lives (the tilings pad different tails with copies of the last point)
+            for slot in range(4):
+                rows2 = _ops.mlp_unpack(pk, 0, a2, n, slot, 64, 0, torch.zeros((n, 64), device=dev), prec=S8)
+                rows3 = _ops.mlp_unpack(pk, 0, a3, n, slot, 64, 0, torch.zeros((n, 64), device=dev), prec=S8)
+                assert torch.equal(rows2, rows3), ("activation unit", slot, n_rays, s)
+                rows2 = _ops.mlp_unpack(pk, 1, g2, n, slot, 64, 0, torch.zeros((n, 64), device=dev), prec=S8)
+                rows3 = _ops.mlp_unpack(pk, 1, g3, n, slot, 64, 0, torch.zeros((n, 64), device=dev), prec=S8)
+                assert torch.equal(rows2, rows3), ("gradient unit", slot, n_rays, s)
+            for (dw2, db2), (dw3, db3), shp in zip(w2, w3, shapes):
+                assert torch.equal(dw2, dw3) and torch.equal(db2, db3), (shp, n_rays, s)
+    finally:
+        nerf.set_precision("fp32")
+
+
 def test_s8_saturates_instead_of_overflowing(dev):
-    """The 8-bit conversions do not saturate in hardware (an e4m3 overflow converts to NaN, an e5m2 one to infinity: measured,
-    scripts/micro/cvt_scale_probe.hip) - the kernels clamp first.  A network driven to activations beyond 448 and gradients beyond
-    57344 / scale must still give finite weight gradients."""
+    """The 8-bit conversions do not saturate in the default mode (an e4m3 overflow converts to NaN, an e5m2 one to infinity: measured,
+    scripts/micro/cvt_scale_probe.hip); the training kernels run them with MODE.FP16_OVFL set, under which they do
+    (scripts/micro/cvt_sat_probe.hip).  A network driven to activations beyond 448 and gradients beyond 57344 / scale must still give
+    finite weight gradients."""
     import nerf
     from nerf import _hip, _ops
     nerf.set_precision("bf16-s16")

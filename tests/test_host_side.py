@@ -84,14 +84,14 @@ def test_argument_validation_needs_no_gpu(hiplib):
     a16, m16, g16 = sizes[_hip.PREC_BF16]
     a8, m8, g8 = sizes[_hip.PREC_BF16_S8]
     # the 8-bit mode runs the 48-point geometry (mlp_geo48.h): 1 KiB units of 64 features per 16-point group, two groups per
-    # 32-point record, whole 384-point workgroup tiles (1000 points = 3 tiles = 36 records); two 1 KiB mask words per wave
-    # tile and masked stage
+    # 32-point record, whole workgroup tiles of whichever tiling pads further - 384 points (1000 points = 3 tiles = 36 records) or 256
+    # (4 tiles = 32 records); two 1 KiB mask words per wave tile and masked stage, wave tiles of the 256-point tiling (4 x 8)
     dd, ww, v = d.num_layers, d.hidden_size, int(d.use_viewdirs)
     khu = ww // 64
     act_units = 1 + v + khu * (1 + (dd - 1) + v) + (ww // 128) * v
     grad_units = (ww // 128) * v + khu * v + (dd - 1) * khu + khu + 1
     # (+ the 256-byte scale / statistics record behind the gradient units)
-    assert a8 == 36 * 2 * act_units * 1024 and g8 == 36 * 2 * grad_units * 1024 + 256 and m8 == 3 * 8 * (dd - 1 + 2 * v) * 2 * 1024
+    assert a8 == 36 * 2 * act_units * 1024 and g8 == 36 * 2 * grad_units * 1024 + 256 and m8 == 4 * 8 * (dd - 1 + 2 * v) * 2 * 1024
     assert a8 < 0.6 * a16 and g8 < 0.6 * g16   # (half the bytes per point; 36 records against the 32-point kernels' 32 tiles)
     # networks outside the 48-point kernels are refused (and train in plain bf16)
     d_deep = _hip.MlpDesc(**{k: getattr(d, k) for k, _ in d._fields_})

@@ -582,8 +582,11 @@ constexpr int kWgLdsBytes16 = 158 * 1024;
 // an iteration is amortised over 2 or 4 of them (the as-shipped 4x128 nets are all "small").
 constexpr int wg_tiles_per_iter(int pieces) { return pieces <= 12 ? 4 : (pieces <= 24 ? 2 : 1); }
 
-constexpr int wg_stages_for(int pieces, int tpi, bool s8) {
-  int s = s8 ? kWgLdsBytes / (pieces * kPieceBytes) : kWgLdsBytes16 / (pieces * kWgPieceStride16);
+// the small layer shapes of the 8-bit kernel (the W = 128 nets') also exist on HALF the LDS, two workgroups per CU: their tile loop is
+// bound by the wait / barrier / LDS round trip of a tile, which a second resident workgroup hides (weight_grad_batch_kernel_s8_small)
+constexpr int kWgLdsBytesSmall = 72 * 1024;
+constexpr int wg_stages_for(int pieces, int tpi, bool s8, int lds_s8 = kWgLdsBytes) {
+  int s = s8 ? lds_s8 / (pieces * kPieceBytes) : kWgLdsBytes16 / (pieces * kWgPieceStride16);
   if (s > 16) s = 16;
   const int per_wave = (pieces + 7) / 8;
   while (s > 2 * tpi && (s - 2 * tpi) * per_wave > 48) --s;  // counted-wait range
@@ -592,8 +595,9 @@ constexpr int wg_stages_for(int pieces, int tpi, bool s8) {
 
 // NTN: 32-row tiles of the output (dY) width; XT: 32-column tiles of the hidden input; PET: 32-column tiles of the
 // appended positional encoding; CUSTOM: dY is the single custom output-gradient piece (fc_rgb / fc_alpha / fc_out)
-template <int NTN_, int XT_, int PET_, bool CUSTOM_, bool S8_ = false>
+template <int NTN_, int XT_, int PET_, bool CUSTOM_, bool S8_ = false, int LDSB_ = kWgLdsBytes>
 struct WgShape {
+  static constexpr int LDS_BYTES = LDSB_;                   // (8-bit kernel) dynamic LDS of the launch this shape is compiled for
   static constexpr int NTN = NTN_, XT = XT_, PET = PET_;
   static constexpr bool CUSTOM = CUSTOM_;
   static constexpr bool S8 = S8_;                          // 8-bit saved tensors: a staged 1 KiB unit holds BOTH pieces of a 32-feature tile
@@ -615,7 +619,7 @@ struct WgShape {
   // tiles per barrier: by the MFMA count of a tile, not by its bytes
   static constexpr int TPI0 = wg_tiles_per_iter(S8 ? 2 * PIECES : PIECES);
   static constexpr int TPI = (K64 && TPI0 < 2) ? 2 : TPI0;
-  static constexpr int STAGES = wg_stages_for(PIECES, TPI, S8); // tile buffers in LDS; STAGES - TPI tiles in flight
+  static constexpr int STAGES = wg_stages_for(PIECES, TPI, S8, LDSB_); // tile buffers in LDS; STAGES - TPI tiles in flight
   static constexpr int PSTRIDE = S8 ? kPieceBytes : kWgPieceStride16;   // LDS distance of consecutive staged pieces
   // Cycles one 32-point tile costs a workgroup of this shape in the 8-bit kernel, fitted to -DDN_WG_STAMP runs (profiles/r02_train_s8.md;
   // measured / model for the W = 256 shapes: (8,0,2) 678 / 746, (8,8,0) 1131 / 1134, (4,8,1) 940 / 1000, (1,8,0) 868 / 904, (8,8,2)
@@ -1055,7 +1059,7 @@ __device__ __forceinline__ void weight_grad_unit(const WgParams& p, int wg, int 
     out_scale = 1.0f / __uint_as_float(*p.scale_word);
     // statistics: wave totals -> LDS -> three atomics per WORKGROUP into one of the record's replicas (same-address atomics
     // serialise: one per wave on one set of counters cost the step 40-90 us)
-    unsigned* wg_stats = reinterpret_cast<unsigned*>(smem + kWgLdsBytes - 128);
+    unsigned* wg_stats = reinterpret_cast<unsigned*>(smem + S::LDS_BYTES - 128);
     __syncthreads();   // every wave has left the tile loop: the tile buffers are free
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -1419,6 +1423,17 @@ __device__ __forceinline__ void weight_grad_dispatch_s8(const WgParams& p, int w
     default: break;
   }
 }
+// shapes 5 .. 10: the layers of a W = 128 net (at most 3 accumulator tiles per wave): 128 VGPRs, two workgroups per CU
+#define DN_WG_SMALL_SHAPES(X) X(5, 1, 4, 0, true) X(6, 4, 0, 2, false) X(7, 4, 4, 0, false) X(8, 4, 4, 2, false) X(9, 2, 4, 1, false) X(10, 1, 2, 0, true)
+constexpr int kWgFirstSmallShape = 5;
+__device__ __forceinline__ void weight_grad_dispatch_s8_small(const WgParams& p, int wg, int n_wg, char* smem) {
+  switch (p.shape) {
+#define X(id, a, b, c, d) case id: weight_grad_unit<WgShape<a, b, c, d, true, kWgLdsBytesSmall>>(p, wg, n_wg, smem); break;
+    DN_WG_SMALL_SHAPES(X)
+#undef X
+    default: break;
+  }
+}
 static int wg_shape_pieces_s8(int shape) {
 #define X(id, a, b, c, d) if (shape == id) return WgShape<a, b, c, d, true>::PIECES;
   DN_WG_SHAPES(X)
@@ -1476,6 +1491,14 @@ __global__ __launch_bounds__(512, 2) void weight_grad_batch_kernel_s8(WgBatch b)
   while (u + 1 < b.n_units && static_cast<int>(blockIdx.x) >= b.wg_begin[u + 1]) ++u;
   const WgParams p = b.u[u];
   weight_grad_dispatch_s8(p, static_cast<int>(blockIdx.x) - b.wg_begin[u], b.wg_begin[u + 1] - b.wg_begin[u], smem);
+}
+
+__global__ __launch_bounds__(512, 4) void weight_grad_batch_kernel_s8_small(WgBatch b) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int u = 0;
+  while (u + 1 < b.n_units && static_cast<int>(blockIdx.x) >= b.wg_begin[u + 1]) ++u;
+  const WgParams p = b.u[u];
+  weight_grad_dispatch_s8_small(p, static_cast<int>(blockIdx.x) - b.wg_begin[u], b.wg_begin[u + 1] - b.wg_begin[u], smem);
 }
 
 __global__ __launch_bounds__(512, 2) void weight_grad_batch_kernel_f32(WgBatch b) {
@@ -1644,10 +1667,13 @@ static int wg_launch_batch(WgBatch& b, const long long* unit_tiles, bool f32, bo
                            size_t scratch_bytes = 0) {
   int rc;
   const int n_units = b.n_units;
-  // (one workgroup per CU.  Two per CU on half the LDS - an instance of the W = 128 layer shapes only, 128 VGPRs - was tried for the
-  // as-shipped nets, whose launches are bound by the wait / barrier / LDS round trip of a tile: the tile loop got 13-26 us shorter,
-  // the reduction of twice as many partials 50 us longer - HISTORY.md section 4.7c)
-  int total_wg = device_cus();
+  // One workgroup per CU - or, for an 8-bit batch of small layer shapes only (the W = 128 nets), two on half the LDS each: those
+  // launches are bound by the wait / barrier / LDS round trip of a tile, which the second resident workgroup hides.  (Round 3 tried
+  // this with the atomics reduction and dropped it - the tile loop got 13-26 us shorter, the reduction of twice as many partials
+  // 50 us longer, HISTORY.md section 4.7c; with partial slabs and the fixed-order second launch the reduction no longer grows that way.)
+  bool small = s8 && !f32 && std::getenv("DEXNERF_WG_ONE_PER_CU") == nullptr;
+  for (int i = 0; i < n_units; ++i) small = small && b.u[i].shape >= kWgFirstSmallShape;
+  int total_wg = device_cus() * (small ? 2 : 1);
   if (total_wg < n_units) total_wg = n_units;
   long long cost[kWgMaxUnits], cost_sum = 0;
   for (int i = 0; i < n_units; ++i) {
@@ -1689,7 +1715,7 @@ static int wg_launch_batch(WgBatch& b, const long long* unit_tiles, bool f32, bo
     }
     two_phase = true;
   }
-  if ((rc = f32 ? wg_attr(weight_grad_batch_kernel_f32) : (s8 ? wg_attr(weight_grad_batch_kernel_s8) : wg_attr(weight_grad_batch_kernel)))) return rc;
+  if ((rc = f32 ? wg_attr(weight_grad_batch_kernel_f32) : (small ? wg_attr(weight_grad_batch_kernel_s8_small) : (s8 ? wg_attr(weight_grad_batch_kernel_s8) : wg_attr(weight_grad_batch_kernel))))) return rc;
 #ifdef DN_WG_STAMP   // diagnostic build: synchronous, allocates, prints - never part of the shipped library
   static unsigned long long* stamp_buf = nullptr;
   const size_t stamp_words = static_cast<size_t>(b.wg_begin[n_units]) * 8 * 8;
@@ -1697,7 +1723,10 @@ static int wg_launch_batch(WgBatch& b, const long long* unit_tiles, bool f32, bo
   (void)hipMemsetAsync(stamp_buf, 0, stamp_words * sizeof(unsigned long long), as_stream(stream));
   for (int i = 0; i < n_units; ++i) b.u[i].stamp = stamp_buf;
 #endif
-  if (s8)
+  if (small)
+    hipLaunchKernelGGL(weight_grad_batch_kernel_s8_small, dim3(static_cast<unsigned>(b.wg_begin[n_units])), dim3(512), kWgLdsBytesSmall,
+                       as_stream(stream), b);
+  else if (s8)
     hipLaunchKernelGGL(weight_grad_batch_kernel_s8, dim3(static_cast<unsigned>(b.wg_begin[n_units])), dim3(512), kWgLdsBytes,
                        as_stream(stream), b);
   else if (f32)
@@ -1744,7 +1773,7 @@ extern "C" size_t dn_mlp_weight_grad_scratch_bytes(const dn_mlp_desc* desc, int 
   const int dim_xyz = 3 + 6 * desc->num_encoding_fn_xyz, dim_dir = 3 + 6 * desc->num_encoding_fn_dir;
   const int widest = W + (dim_xyz > dim_dir ? dim_xyz : dim_dir);
   const int n_units = n_networks * (desc->num_layers + (desc->use_viewdirs ? 4 : 1));
-  int total_wg = dn::device_cus();
+  int total_wg = dn::device_cus() * (W <= 128 ? 2 : 1);   // (the W = 128 nets' 8-bit launch: two workgroups per CU)
   if (total_wg < n_units) total_wg = n_units;
   return static_cast<size_t>(total_wg + n_units) * static_cast<size_t>(dn::wg_part_stride(W, widest)) * sizeof(float);
 }

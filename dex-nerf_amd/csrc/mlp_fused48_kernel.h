@@ -184,8 +184,17 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_forward48_kernel(FwdPar
   pipe.wave = wave;
 #pragma unroll
   for (int ph = 0; ph < (PH == kPhasePieces ? kRingPhases - 1 : kRingPhases - 2); ++ph) pipe.issue_phase();
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __syncthreads();
+  if constexpr (PH == kPhasePieces && kG48LeaderDma && kG48AsmReads) {
+    // The first barrier period needs what every later one needs: phases 0 and 1 landed (Pipe48::phase_begin).  A fetching wave leaves
+    // its eight youngest loads - its shares of phases 2 and 3 - in flight (everything older - the inputs - has then landed); waves 4-7
+    // have nothing but their input DMAs outstanding and wait for all of them.  (A launch of one or two tiles per workgroup - a training
+    // step of the small nets - paid the flight time of two phases here.)
+    g48_prologue_wait(wave);
+    __builtin_amdgcn_s_barrier();
+  } else {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 #ifdef DN_EXP_HALF   // timing experiment only: one wave per SIMD does the work (what a wave sustains ALONE); 1: waves 0-3, 2: waves 4-7 (+ the fetching by 0-3 is lost: combine with DN_EXP_NODMA)
   if ((DN_EXP_HALF == 1) ? wave >= 4 : wave < 4) return;
 #endif

@@ -43,6 +43,21 @@ using PipeGeo48 = PipeGeometry<kG48AsmReads, kG48LeaderDma, true, kPrefetch>;
 template <int WAVES>
 using Pipe48 = PipeT<WAVES, PipeGeo48>;
 
+// End of a kernel's prologue where the barrier period is one phase (PipeT::phase_begin): kRingPhases - 1 phases were requested, the
+// first period needs phases 0 and 1.  Fetching waves (0-3: four loads per phase) keep their eight youngest loads in flight - VMEM ops
+// retire in order, so everything they issued earlier (input rows, mask words) has landed too; waves 4-7 issued no weight loads and
+// wait for all they have.  LDS stores of the prologue (bias rows, tables) are waited for as well.  Branch inside the statement.
+__device__ __forceinline__ void g48_prologue_wait(unsigned wave) {
+  const unsigned fetcher = __builtin_amdgcn_readfirstlane(wave < 4 ? 1u : 0u);
+  asm volatile("s_cmp_eq_u32 %0, 0\n\t"
+               "s_cbranch_scc1 .Ldn_prol_all%=\n\t"
+               "s_waitcnt vmcnt(8) lgkmcnt(0)\n\t"
+               "s_branch .Ldn_prol_done%=\n"
+               ".Ldn_prol_all%=:\n\t"
+               "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+               ".Ldn_prol_done%=:" ::"s"(fetcher) : "scc", "memory");
+}
+
 // F = 1: bf16, 2: fp16 (Prec<F> of mlp_device.h): same MFMA rate and layouts
 template <int F>
 __device__ __forceinline__ f32x4 mfma48(typename Prec<F>::BPiece a, typename Prec<F>::BPiece b, f32x4 c) {

@@ -144,8 +144,13 @@ __global__ __launch_bounds__(kG48Waves * 64, 2) void mlp_backward48_kernel(Bwd48
   if (n_masks > 1) issue_mask(blockIdx.x, 1);
 #pragma unroll
   for (int ph = 0; ph < kRingPhases - 1; ++ph) pipe.issue_phase();
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __syncthreads();
+  if constexpr (kG48LeaderDma && kG48AsmReads) {   // phases 0 and 1 landed is all the first barrier period needs (mlp_stage48.h g48_prologue_wait)
+    g48_prologue_wait(wave);
+    __builtin_amdgcn_s_barrier();
+  } else {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   pipe.slot_nxt = 0;
   pipe.rda_cur = pipe.ring_addr + lane * 16;
   pipe.slot_cur_base = pipe.ring_addr;       // phase 0 lives in slot 0: phase_begin() of phase 0 turns this into rda_cur

@@ -2194,7 +2194,8 @@ def test_s8_training_kernels_on_two_point_groups_per_wave_equal_the_three_group_
     ones (csrc/mlp_geo48.h g48_train_groups: fewer idle compute units, no short last round).  Same per-point arithmetic, the same saved
     units at the same addresses (the layout is by group), other mask-word addresses (per wave tile) that forward and backward agree on:
     radiance field, saved activations, saved gradients and weight gradients must be IDENTICAL to the three-group instances' - forced
-    either way with DEXNERF_G48_TRAIN_GROUPS - on a ragged point count; and the rule itself must pick what it documents."""
+    either way with DEXNERF_G48_TRAIN_GROUPS - on ragged point counts (the default rule's own choice runs in every other 8-bit test:
+    small launches take two groups, the 4096-ray steps three)."""
     import nerf
     from nerf import _hip, _ops
     nerf.set_precision("bf16")

@@ -139,7 +139,9 @@ def kernel_isa_sha16(precision):
     """sha256 (first 16 hex digits) of the instruction stream of the headline kernel instance in the library this process loads
     (scripts/codeobj.py: code objects out of the .so, llvm-objdump): the identity of the kernel BINARY.  None without the LLVM tools."""
     try:
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts"))
+        scripts = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts")
+        if scripts not in sys.path:
+            sys.path.insert(0, scripts)
         import codeobj
         lib = os.environ.get("DEXNERF_HIP_LIB") or codeobj.DEFAULT_LIB
         return codeobj.kernel_isa_sha16(headline_kernel_name(precision) + "(", lib)

@@ -4,7 +4,9 @@ import csv, glob, json, sys
 from collections import defaultdict
 
 mode = sys.argv[1]
-KERNELS = ("mlp_forward_kernel", "mlp_backward_kernel", "mlp_forward48_kernel", "mlp_backward48_kernel", "weight_grad_batch_kernel")
+import os
+KERNELS = tuple(os.environ["PMC_KERNELS"].split(";")) if os.environ.get("PMC_KERNELS") else \
+    ("mlp_forward_kernel", "mlp_backward_kernel", "mlp_forward48_kernel", "mlp_backward48_kernel", "weight_grad_batch_kernel")
 out = {"mode": mode, "kernels": {}}
 for name in ("fetch", "write", "mfma", "sqA", "sqB"):
     cc = glob.glob(f"gpurun_out/pmc_train_{mode}_{name}/*/*counter_collection.csv")

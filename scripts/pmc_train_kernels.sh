@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 pass() {  # name, counters...
   name=$1; shift
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_train_${mode}_$name -- python3 scripts/train_bench.py $mode 4096 > gpurun_out/pmc_train_${mode}_$name.log 2>&1 || echo "pass $name failed (see gpurun_out/pmc_train_${mode}_$name.log)"
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_train_${mode}_$name -- python3 ${PMC_TRAIN_CMD:-scripts/train_bench.py $mode 4096} > gpurun_out/pmc_train_${mode}_$name.log 2>&1 || echo "pass $name failed (see gpurun_out/pmc_train_${mode}_$name.log)"
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE

@@ -13,8 +13,11 @@ src, tag = sys.argv[1], sys.argv[2]
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(repo, "profiles")
 os.makedirs(out_dir, exist_ok=True)
-stats = glob.glob(os.path.join(src, "*_kernel_stats.csv"))[0]
-trace = glob.glob(os.path.join(src, "*_kernel_trace.csv"))[0]
+# (a gpurun_out/ directory collects the files of every run that wrote there: the NEWEST pair is the run meant)
+newest = lambda pat: max(glob.glob(os.path.join(src, pat)), key=os.path.getmtime)   # noqa: E731
+stats = newest("*_kernel_stats.csv")
+trace = newest("*_kernel_trace.csv")
+assert os.path.basename(stats).split("_")[0] == os.path.basename(trace).split("_")[0], (stats, trace)
 rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)

@@ -1,3 +1,8 @@
+#!/bin/bash
+# Developer tool (GPU box): timing-only ablations of the training forward's epilogue on ONE box, alternated twice
+# (profiles/r04_headline_schedule.md section 8).  Build the variants first:
+#   scripts/build_exp.sh tf_nomask "-DDN_EXP_TF_NOMASK=1" mlp_fused48.hip ; scripts/build_exp.sh tf_nounit "-DDN_EXP_TF_NOUNIT=1" mlp_fused48.hip
+#   scripts/build_exp.sh tf_noepi "-DDN_EXP_NOEPI=1" mlp_fused48.hip ; scripts/build_exp.sh tf_none "-DDN_EXP_NOEPI=1 -DDN_EXP_TF_NOUNIT=1 -DDN_EXP_TF_NOMASK=1" mlp_fused48.hip
 for r in 1 2; do
 for tag in base tf_nomask tf_nounit tf_noepi tf_none; do
   unset DEXNERF_HIP_LIB
